@@ -1,0 +1,167 @@
+"""The oracle (oracle/press_oracle.c) pinned against the golden vectors generated from
+the real reference (tests/golden/make_golden.py) - CPU only."""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _libs
+from honours_amd import synth
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()[:32]
+
+
+def test_three_reads(oracle, golden_dir):
+    """data/three-reads.blow5: stream length, FNV-1a and sha256 per read and method
+    (sums equal the press_bytes column of press/test's TSV)."""
+    meta = json.load(open(os.path.join(golden_dir, "three_reads.json")))
+    sig = np.fromfile(os.path.join(golden_dir, "three_reads.i16.bin"), dtype=np.int16)
+    assert [r["n"] for r in meta["reads"]] == [7329, 155185, 95350]
+    o = 0
+    totals = {}
+    for r in meta["reads"]:
+        s = sig[o:o + r["n"]]
+        o += r["n"]
+        for m, e in r["methods"].items():
+            assert oracle.bound(m, r["n"]) == e["bound"], m
+            ret, c = oracle.press(m, s)
+            assert ret == 0, m
+            if m in _libs.DETERMINISTIC:
+                assert len(c) == e["len"], m
+                assert "%08x" % _libs.fnv1a32(c) == e["fnv1a32"], m
+                assert sha(c) == e["sha256_32"], m
+                totals[m] = totals.get(m, 0) + len(c)
+            ret, back = oracle.depress(m, c, r["n"])
+            assert ret == 0 and np.array_equal(back, s), m
+    # press_bytes of the reference's own run on this file
+    assert totals["svb12_zd"] == 290111
+    assert totals["svb_zd"] == 322344
+    assert totals["vbe21_zd"] == 257924
+    assert totals["shuffman_vbe21_zd"] == 175227
+    assert totals["hasgam_vbsse21_zdq"] == 257953
+
+
+def test_micro_kats(oracle, golden_dir):
+    vec = json.load(open(os.path.join(golden_dir, "micro_kats.json")))["vectors"]
+    assert len(vec) >= 15
+    for v in vec:
+        s = np.array(v["input"], dtype=np.int16)
+        for m, hexs in v["streams"].items():
+            want = bytes.fromhex(hexs)
+            ret, c = oracle.press(m, s, cap=max(len(want) + 64, int(oracle.bound(m, len(s)))))
+            assert ret == 0 and c == want, (v["name"], m)
+            if m.startswith("shuffman") and len(s) == 1:
+                continue
+            ret, back = oracle.depress(m, want, len(s))
+            assert ret == 0 and np.array_equal(back, s), (v["name"], m)
+
+
+def test_survey_appendix_vectors(oracle):
+    """the hex vectors quoted in SURVEY.md appendix A"""
+    s = [500, 503, 499, 499, 900, 901, 300, 300, 305]
+    assert oracle.press("svb12_zd", s)[1].hex() == "5100e803060700220302b104000a"
+    assert oracle.press("svb_zd", s)[1].hex() == "011100e803060700220302b104000a"
+    # NB X_bound(9) = 19 < 24: the reference's bound is a heuristic (press.c:2575) that the
+    # harness never checks (test.c:1788); the oracle honours the capacity it is given
+    assert oracle.press("vbe21_zd", s, cap=int(oracle.bound("vbe21_zd", 9)))[0] == -1
+    assert oracle.press("vbe21_zd", s, cap=64)[1].hex() == "e8030200000003000000050000002203b10406070002000a"
+    assert oracle.press("shuffman_vbe21_zd", s, cap=64)[1].hex() == \
+        "e8030200000003000000050000002203b104000000060f927300"
+    assert oracle.press("hasgam_vbsse21_zdq", [512, 544, 480, 480, 1056, 1056, 96, 128])[1].hex() == \
+        "00" + "0800000000000000" + "05" + "2000" + "00000000" + "02030024003b02"
+
+
+def test_svb32_issue42(oracle, golden_dir):
+    """press/streamvbyte/tests/unit.c:283 - decode 29159 values from 36494 bytes,
+    re-encode, get the same bytes back."""
+    a = np.fromfile(os.path.join(golden_dir, "svb32_issue42.bin"), dtype=np.uint8)
+    assert a.size == 36494
+    buf = np.concatenate([a, np.zeros(16, np.uint8)])
+    vals = np.zeros(29159, dtype=np.uint32)
+    used = oracle.lib.po_svb32_decode(buf.ctypes.data, 29159, vals.ctypes.data)
+    assert used == 36494
+    out = np.zeros(36494 + 64, dtype=np.uint8)
+    n = oracle.lib.po_svb32_encode(vals.ctypes.data, 29159, out.ctypes.data)
+    assert n == 36494 and np.array_equal(out[:n], a)
+
+
+def test_synth_kats(oracle, golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "synth_kats.json")))["cases"]
+    for c in cases:
+        s = synth.synth_read(c["seed"], c["read"], c["n"], c["first"])
+        assert sha(s.tobytes()) == c["sha256_32_signal"]
+        for m, e in c["methods"].items():
+            ret, out = oracle.press(m, s)
+            assert ret == 0, (m, c["n"])
+            if m in _libs.DETERMINISTIC:
+                assert len(out) == e["len"] and sha(out) == e["sha256_32"], (m, c["n"])
+            if m.startswith("shuffman") and len(out) <= 6 + 4:
+                continue
+            ret, back = oracle.depress(m, out, c["n"])
+            assert ret == 0 and np.array_equal(back, s), (m, c["n"])
+
+
+def test_bitpack_roundtrip(oracle):
+    rng = np.random.default_rng(3)
+    for width, dt in ((16, np.uint16), (32, np.uint32)):
+        for bits in range(0, width + 1):
+            n = int(rng.integers(1, 50))
+            hi = (1 << bits) - 1
+            v = rng.integers(0, hi + 1, size=n, dtype=np.uint64).astype(dt)
+            if bits:
+                v[0] = hi
+            out = np.zeros(8 + n * 4, dtype=np.uint8)
+            ln = oracle.lib.po_uint_pack(v.ctypes.data, n, width, out.ctypes.data)
+            assert out[0] == bits and ln == 1 + (n * bits + 7) // 8
+            back = np.zeros(n, dtype=dt)
+            used = oracle.lib.po_uint_unpack(out.ctypes.data, n, width, back.ctypes.data)
+            assert used == ln and np.array_equal(back, v)
+
+
+def test_table_matches_bitlength_list(oracle):
+    """NA12878_zd.huffman: 256 symbols, code lengths 4..22"""
+    t = oracle.table()
+    lens = [l for l, _ in t]
+    assert min(lens) == 4 and max(lens) == 22
+    # Kraft equality: a complete prefix code
+    assert sum(2.0 ** -l for l in lens) == 1.0
+
+
+@pytest.mark.skipif(not _libs.have_reference(), reason="oracle/_ref not built (no /root/reference here)")
+def test_oracle_vs_reference_fuzz(oracle):
+    """restatement == reference on randomised inputs, every method, incl. bounds"""
+    ref = _libs.reference()
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    saved = os.dup(2)
+    os.dup2(devnull, 2)  # the reference prints diagnostics (press.c:3262)
+    try:
+        rng = np.random.default_rng(11)
+        for it in range(150):
+            n = int(rng.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 33, 64, 100, 1000, 5000]))
+            exr = float(rng.choice([0, 0.001, 0.01, 0.05, 0.15]))
+            d = rng.integers(-60, 60, size=n)
+            ex = rng.random(n) < exr
+            d[ex] = rng.integers(-40000, 40000, size=int(ex.sum()))
+            s = (np.cumsum(d) + 500).astype(np.int64).astype(np.uint16).view(np.int16)
+            if it % 7 == 0:
+                s = ((s >> 5) << 5).astype(np.int16)
+            z = np.zeros(n, dtype=np.uint16)
+            oracle.lib.po_zigdelta_u16(s.ctypes.data, n, z.ctypes.data)
+            for m in _libs.METHODS:
+                if m.startswith("shuffman") and int((z[1:] <= 255).sum()) == 0:
+                    continue
+                cap = int(ref.bound(m, n)) + 8 * n + 1024
+                rr, rc = ref.press(m, s, cap=cap)
+                oo, oc = oracle.press(m, s, cap=cap)
+                assert (rr, rc) == (oo, oc), (m, n, exr)
+                assert oracle.bound(m, n) == ref.bound(m, n)
+                if rr == 0:
+                    dr, dd = oracle.depress(m, rc, n)
+                    assert dr == 0 and np.array_equal(dd, s), (m, n)
+    finally:
+        os.dup2(saved, 2)
