@@ -1,0 +1,988 @@
+// press_abi.hip - host side of libpress_hip.so: the C ABI of include/press_hip.h.
+//
+// Mirrors the reference's per-method C interface (press/press.h) on top of the batch
+// kernels in press_kernels.hip.  There is NO CPU implementation of any codec in this
+// file: every X_press / X_depress runs the HIP kernels and fails (-1 / *nout = 0)
+// when the device is unavailable.  The only third-party stage is libzstd for the
+// zstd_* compositions, which the reference itself delegates to libzstd (press.c:1464).
+
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/press_hip.h"
+#include "press_internal.h"
+
+using namespace ph;
+
+// ------------------------------------------------------------------ errors
+
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIPCHK(call)                                                                        \
+	do {                                                                                \
+		hipError_t e_ = (call);                                                     \
+		if (e_ != hipSuccess)                                                       \
+			return fail(PRESS_HIP_EHIP, "%s: %s", #call, hipGetErrorString(e_)); \
+	} while (0)
+
+extern "C" const char *press_hip_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------ context
+
+namespace {
+
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	// grow-only; contents are not preserved
+	int reserve(size_t n)
+	{
+		if (n <= cap)
+			return 0;
+		if (p)
+			(void) hipFree(p);
+		p = nullptr;
+		cap = 0;
+		size_t want = n + n / 8 + 4096;
+		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess)
+			return fail(PRESS_HIP_EHIP, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+		cap = want;
+		return 0;
+	}
+	void release()
+	{
+		if (p)
+			(void) hipFree(p);
+		p = nullptr;
+		cap = 0;
+	}
+};
+
+struct Ctx {
+	bool ready = false;
+	int device = -1;
+	hipStream_t own = nullptr;
+	hipStream_t user = nullptr;
+	bool use_user = false;
+	// scratch shared by both modes
+	DevBuf meta, ex_pos, ex_val, low, huff;
+	// staging for host-pointer calls
+	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn;
+	// static Huffman table currently on the device
+	bool have_table = false;
+	uint32_t tlen[256];
+	uint64_t tbits[256];
+
+	hipStream_t stream() const { return use_user ? user : own; }
+};
+
+Ctx g;
+
+int ctx_init()
+{
+	if (g.ready)
+		return 0;
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev == 0)
+		return fail(PRESS_HIP_EHIP, "no HIP device: %s", hipGetErrorString(e));
+	if (g.device < 0)
+		HIPCHK(hipGetDevice(&g.device));
+	HIPCHK(hipSetDevice(g.device));
+	HIPCHK(hipStreamCreateWithFlags(&g.own, hipStreamNonBlocking));
+	g.ready = true;
+	return 0;
+}
+
+// ---- zstd, loaded lazily (third party; the reference links -lzstd, press/Makefile:3) ----
+struct Zstd {
+	bool tried = false;
+	size_t (*compress)(void *, size_t, const void *, size_t, int) = nullptr;
+	size_t (*decompress)(void *, size_t, const void *, size_t) = nullptr;
+	size_t (*bound)(size_t) = nullptr;
+	unsigned (*is_error)(size_t) = nullptr;
+} zs;
+
+bool zstd_open()
+{
+	if (zs.tried)
+		return zs.compress != nullptr;
+	zs.tried = true;
+	const char *names[] = { "/opt/conda/lib/libzstd.so.1", "libzstd.so.1", "libzstd.so", nullptr };
+	for (int i = 0; names[i]; i++) {
+		void *h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+		if (!h)
+			continue;
+		zs.compress = (decltype(zs.compress)) dlsym(h, "ZSTD_compress");
+		zs.decompress = (decltype(zs.decompress)) dlsym(h, "ZSTD_decompress");
+		zs.bound = (decltype(zs.bound)) dlsym(h, "ZSTD_compressBound");
+		zs.is_error = (decltype(zs.is_error)) dlsym(h, "ZSTD_isError");
+		if (zs.compress && zs.decompress && zs.bound && zs.is_error)
+			return true;
+		zs.compress = nullptr;
+	}
+	return false;
+}
+
+uint64_t zstd_bound_(uint64_t n)
+{
+	if (zstd_open())
+		return zs.bound(n);
+	// zstd.h ZSTD_COMPRESSBOUND
+	return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0);
+}
+
+// ---- bounds: the reference's formulas ----
+uint32_t svb16_keylen(uint32_t n) { return (n >> 3) + (((n & 7) + 7) >> 3); }
+uint64_t bound_svb32(uint32_t n) { return (uint64_t) (n + 3) / 4 + (uint64_t) n * 4 + 16; }    // streamvbyte.h:35
+uint64_t bound_svb16(uint32_t n) { return (uint64_t) svb16_keylen(n) + (uint64_t) n * 4 + 16; } // streamvbyte.h:42
+uint64_t bound_vb1e2(uint32_t m) { return (uint64_t) (1 + m * 0.2 * 6 + m * 0.8); }            // press.c:2575
+uint64_t bound_vbzd(uint32_t n) { return 2 + bound_vb1e2(n - 1); }                             // press.c:3411
+
+bool is_shuff(int m) { return m >= PRESS_HIP_SHUFF_VBE21_ZD && m <= PRESS_HIP_SHUFF_VBSSE21_ZD; }
+bool is_svb(int m) { return m == PRESS_HIP_SVB12 || m == PRESS_HIP_SVB12_ZD || m == PRESS_HIP_SVB_ZD; }
+bool is_zstd(int m)
+{
+	return m == PRESS_HIP_ZSTD_SVB_ZD || m == PRESS_HIP_ZSTD_SVB12_ZD || m == PRESS_HIP_ZSTD_HASGAM_ZDQ;
+}
+bool is_ex(int m) { return m >= PRESS_HIP_VBE21_ZD && m <= PRESS_HIP_HASGAM_ZDQ; }
+
+int exfmt_of(int m)
+{
+	switch (m) {
+	case PRESS_HIP_VBE21_ZD: case PRESS_HIP_SHUFF_VBE21_ZD:     return EXF_VBE21;
+	case PRESS_HIP_VBBE21_ZD: case PRESS_HIP_SHUFF_VBBE21_ZD:   return EXF_VBBE21;
+	case PRESS_HIP_VBSBE21_ZD: case PRESS_HIP_SHUFF_VBSBE21_ZD: return EXF_VBSBE21;
+	case PRESS_HIP_VBSSE21_ZD: case PRESS_HIP_SHUFF_VBSSE21_ZD: return EXF_VBSSE21;
+	default:                                                    return EXF_EXZD;
+	}
+}
+
+// ---- static Huffman table -> device form ----
+int upload_table(const uint32_t len[256], const uint64_t bits[256])
+{
+	if (g.have_table && !memcmp(len, g.tlen, sizeof g.tlen) && !memcmp(bits, g.tbits, sizeof g.tbits))
+		return 0;
+	std::vector<HuffDev> hv(1);
+	HuffDev &h = hv[0];
+	memset(&h, 0xFF, sizeof h); // lut = 0xFFFF, child/leaf = -1
+	int nnodes = 1;
+	for (int s = 0; s < 256; s++) {
+		const uint32_t l = len[s];
+		if (l == 0 || l > 24)
+			return fail(PRESS_HIP_EARG, "Huffman table: symbol %d has code length %u (need 1..24)", s, l);
+		h.enc[s] = (uint32_t) (bits[s] & 0xFFFFFFu) | (l << 24);
+		int p = 0;
+		for (uint32_t k = 0; k < l; k++) {
+			const int b = (int) ((bits[s] >> k) & 1);
+			if (h.leaf[p] >= 0)
+				return fail(PRESS_HIP_EARG, "Huffman table: not a prefix code");
+			if (h.child[p][b] < 0) {
+				if (nnodes >= 1024)
+					return fail(PRESS_HIP_EARG, "Huffman table: too many nodes");
+				h.child[p][b] = (int16_t) nnodes++;
+			}
+			p = h.child[p][b];
+		}
+		if (h.child[p][0] >= 0 || h.child[p][1] >= 0)
+			return fail(PRESS_HIP_EARG, "Huffman table: not a prefix code");
+		h.leaf[p] = (int16_t) s;
+		if (l <= (uint32_t) HUF_LUT_BITS) {
+			const uint32_t step = 1u << l;
+			for (uint32_t i = (uint32_t) bits[s] & (step - 1); i < (1u << HUF_LUT_BITS); i += step)
+				h.lut[i] = (uint16_t) (s | (l << 8));
+		}
+	}
+	if (g.huff.reserve(sizeof(HuffDev)))
+		return PRESS_HIP_EHIP;
+	HIPCHK(hipMemcpy(g.huff.p, &h, sizeof h, hipMemcpyHostToDevice));
+	memcpy(g.tlen, len, sizeof g.tlen);
+	memcpy(g.tbits, bits, sizeof g.tbits);
+	g.have_table = true;
+	return 0;
+}
+
+int parse_table_file(FILE *fp, uint32_t len[256], uint64_t bits[256]);
+
+int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool decode)
+{
+	if (g.meta.reserve(((size_t) nreads + 1) * sizeof(ReadMeta)))
+		return PRESS_HIP_EHIP;
+	if (is_ex(method)) {
+		if (g.ex_pos.reserve((total_samples + 64) * 4) || g.ex_val.reserve((total_samples + 64) * 4))
+			return PRESS_HIP_EHIP;
+		if (decode && is_shuff(method) && g.low.reserve(total_samples + 64))
+			return PRESS_HIP_EHIP;
+	}
+	return 0;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ library control
+
+extern "C" int press_hip_set_device(int device)
+{
+	if (g.ready && device != g.device)
+		press_hip_shutdown();
+	g.device = device;
+	return ctx_init();
+}
+
+extern "C" int press_hip_set_stream(void *stream)
+{
+	int rc = ctx_init();
+	if (rc)
+		return rc;
+	g.user = (hipStream_t) stream;
+	g.use_user = stream != nullptr;
+	return 0;
+}
+
+extern "C" void *press_hip_get_stream(void)
+{
+	if (ctx_init())
+		return nullptr;
+	return (void *) g.stream();
+}
+
+extern "C" int press_hip_synchronize(void)
+{
+	int rc = ctx_init();
+	if (rc)
+		return rc;
+	HIPCHK(hipStreamSynchronize(g.stream()));
+	return 0;
+}
+
+extern "C" void press_hip_shutdown(void)
+{
+	if (!g.ready)
+		return;
+	(void) hipSetDevice(g.device);
+	(void) hipStreamSynchronize(g.own);
+	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.sig, &g.off, &g.nsamp,
+			  &g.arena, &g.arena_off, &g.lens, &g.lens2, &g.outn };
+	for (DevBuf *b : all)
+		b->release();
+	(void) hipStreamDestroy(g.own);
+	g.own = nullptr;
+	g.user = nullptr;
+	g.use_user = false;
+	g.have_table = false;
+	g.ready = false;
+}
+
+extern "C" int press_hip_set_table(const uint32_t len[256], const uint64_t bits[256])
+{
+	int rc = ctx_init();
+	if (rc)
+		return rc;
+	return upload_table(len, bits);
+}
+
+extern "C" int press_hip_load_table_file(const char *path)
+{
+	uint32_t len[256];
+	uint64_t bits[256];
+	FILE *fp = fopen(path, "rb");
+	if (!fp)
+		return fail(PRESS_HIP_EARG, "cannot open %s", path);
+	int rc = parse_table_file(fp, len, bits);
+	fclose(fp);
+	if (rc)
+		return rc;
+	return press_hip_set_table(len, bits);
+}
+
+extern "C" uint64_t press_hip_bound(int method, uint32_t n)
+{
+	switch (method) {
+	case PRESS_HIP_SVB12:
+	case PRESS_HIP_SVB12_ZD:        return bound_svb16(n);                          // press.c:1568,1678
+	case PRESS_HIP_SVB_ZD:          return bound_svb32(n);                          // press.c:1585
+	case PRESS_HIP_ZSTD_SVB_ZD:     return zstd_bound_(4 + bound_svb32(n));         // press.c:1860
+	case PRESS_HIP_ZSTD_SVB12_ZD:   return zstd_bound_(4 + bound_svb16(n));         // press.c:2020
+	case PRESS_HIP_HASGAM_ZDQ:      return bound_svb32((uint32_t) bound_vbzd(n));   // press.c:8461
+	case PRESS_HIP_ZSTD_HASGAM_ZDQ: return zstd_bound_(bound_svb32((uint32_t) bound_vbzd(n)));
+	default:
+		if (is_ex(method))
+			return bound_vbzd(n);                                           // press.c:3411,4409
+	}
+	return 0;
+}
+
+extern "C" uint64_t press_hip_workspace_bytes(int method, uint64_t total_samples, uint32_t nreads)
+{
+	uint64_t b = ((uint64_t) nreads + 1) * sizeof(ReadMeta);
+	if (is_ex(method))
+		b += 2 * (total_samples + 64) * 4;
+	if (is_shuff(method))
+		b += total_samples + 64 + sizeof(HuffDev);
+	return b;
+}
+
+// ------------------------------------------------------------------ batch API
+
+static int launch_press(int method, const BatchArgs &a, hipStream_t s)
+{
+	switch (method) {
+	case PRESS_HIP_SVB12:    launch_svb_encode(a, false, false, s); break;
+	case PRESS_HIP_SVB12_ZD: launch_svb_encode(a, false, true, s); break;
+	case PRESS_HIP_SVB_ZD:   launch_svb_encode(a, true, true, s); break;
+	default:
+		launch_ex_encode(a, exfmt_of(method), is_shuff(method), s);
+	}
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess)
+		return fail(PRESS_HIP_EHIP, "kernel launch: %s", hipGetErrorString(e));
+	return 0;
+}
+
+static int launch_depress(int method, const DecodeArgs &a, hipStream_t s)
+{
+	switch (method) {
+	case PRESS_HIP_SVB12:    launch_svb_decode(a, false, false, s); break;
+	case PRESS_HIP_SVB12_ZD: launch_svb_decode(a, false, true, s); break;
+	case PRESS_HIP_SVB_ZD:   launch_svb_decode(a, true, true, s); break;
+	default:
+		launch_ex_decode(a, exfmt_of(method), is_shuff(method), s);
+	}
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess)
+		return fail(PRESS_HIP_EHIP, "kernel launch: %s", hipGetErrorString(e));
+	return 0;
+}
+
+static int check_method(int method)
+{
+	if (method < 0 || method >= PRESS_HIP_NMETHODS || is_zstd(method))
+		return fail(PRESS_HIP_EARG, "method %d is not available in the batch API", method);
+	if (is_shuff(method) && !g.have_table)
+		return fail(PRESS_HIP_ENOTABLE, "static-Huffman method without a table (press_hip_load_table_file)");
+	return 0;
+}
+
+extern "C" int press_hip_press_batch(int method, const int16_t *sig, const uint64_t *off, const uint32_t *n,
+				     uint32_t nreads, uint64_t total_samples, uint8_t *out,
+				     const uint64_t *out_off, uint64_t *out_len, int device_resident)
+{
+	int rc = ctx_init();
+	if (rc)
+		return rc;
+	if ((rc = check_method(method)))
+		return rc;
+	if (nreads == 0)
+		return 0;
+	if (!sig || !off || !n || !out || !out_off || !out_len)
+		return fail(PRESS_HIP_EARG, "NULL argument");
+	hipStream_t s = g.stream();
+	if ((rc = reserve_scratch(method, total_samples, nreads, false)))
+		return rc;
+
+	BatchArgs a;
+	memset(&a, 0, sizeof a);
+	a.nreads = nreads;
+	a.meta = (ReadMeta *) g.meta.p;
+	a.ex_pos = (uint32_t *) g.ex_pos.p;
+	a.ex_val = (uint32_t *) g.ex_val.p;
+	a.huff = (const HuffDev *) g.huff.p;
+
+	if (device_resident) {
+		if ((uintptr_t) sig & 15)
+			return fail(PRESS_HIP_EARG, "sig must be 16-byte aligned");
+		a.sig = sig;
+		a.off = off;
+		a.nsamp = n;
+		a.out = out;
+		a.out_off = out_off;
+		a.out_len = out_len;
+		return launch_press(method, a, s);
+	}
+
+	// host pointers: stage, run, copy back, synchronise
+	for (uint32_t r = 0; r < nreads; r++) {
+		if (off[r] & 7)
+			return fail(PRESS_HIP_EARG, "off[%u] = %llu is not a multiple of 8 samples", r,
+				    (unsigned long long) off[r]);
+		if (off[r] + n[r] > total_samples)
+			return fail(PRESS_HIP_EARG, "read %u ends beyond total_samples", r);
+		if (out_off[r + 1] < out_off[r])
+			return fail(PRESS_HIP_EARG, "out_off must be non-decreasing");
+	}
+	const uint64_t a0 = out_off[0], a1 = out_off[nreads];
+	if (g.sig.reserve(total_samples * 2 + 64) || g.off.reserve((size_t) nreads * 8) ||
+	    g.nsamp.reserve((size_t) nreads * 4) ||
+	    g.arena.reserve(a1 - a0 + 64) || g.arena_off.reserve(((size_t) nreads + 1) * 8) ||
+	    g.lens.reserve((size_t) nreads * 8))
+		return PRESS_HIP_EHIP;
+	std::vector<uint64_t> rel(nreads + 1);
+	for (uint32_t r = 0; r <= nreads; r++)
+		rel[r] = out_off[r] - a0;
+	HIPCHK(hipMemcpyAsync(g.sig.p, sig, total_samples * 2, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(g.off.p, off, (size_t) nreads * 8, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(g.nsamp.p, n, (size_t) nreads * 4, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(g.arena_off.p, rel.data(), ((size_t) nreads + 1) * 8, hipMemcpyHostToDevice, s));
+	HIPCHK(hipStreamSynchronize(s)); // rel goes out of scope; sig is pageable anyway
+	a.sig = (const int16_t *) g.sig.p;
+	a.off = (const uint64_t *) g.off.p;
+	a.nsamp = (const uint32_t *) g.nsamp.p;
+	a.out = (uint8_t *) g.arena.p;
+	a.out_off = (const uint64_t *) g.arena_off.p;
+	a.out_len = (uint64_t *) g.lens.p;
+	if ((rc = launch_press(method, a, s)))
+		return rc;
+	HIPCHK(hipMemcpyAsync(out_len, g.lens.p, (size_t) nreads * 8, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	for (uint32_t r = 0; r < nreads; r++) {
+		if (out_len[r] == PRESS_HIP_FAILED || out_len[r] == 0)
+			continue;
+		HIPCHK(hipMemcpyAsync(out + out_off[r], (uint8_t *) g.arena.p + rel[r], out_len[r],
+				      hipMemcpyDeviceToHost, s));
+	}
+	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}
+
+extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint64_t *in_off,
+				       const uint64_t *in_len, uint32_t nreads, int16_t *sig,
+				       const uint64_t *off, const uint32_t *n, uint64_t total_samples,
+				       uint32_t *out_n, int device_resident)
+{
+	int rc = ctx_init();
+	if (rc)
+		return rc;
+	if ((rc = check_method(method)))
+		return rc;
+	if (nreads == 0)
+		return 0;
+	if (!in || !in_off || !in_len || !sig || !off || !n || !out_n)
+		return fail(PRESS_HIP_EARG, "NULL argument");
+	hipStream_t s = g.stream();
+	if ((rc = reserve_scratch(method, total_samples, nreads, true)))
+		return rc;
+
+	DecodeArgs a;
+	memset(&a, 0, sizeof a);
+	a.nreads = nreads;
+	a.meta = (ReadMeta *) g.meta.p;
+	a.ex_pos = (uint32_t *) g.ex_pos.p;
+	a.ex_val = (uint32_t *) g.ex_val.p;
+	a.low = (uint8_t *) g.low.p;
+	a.huff = (const HuffDev *) g.huff.p;
+
+	if (device_resident) {
+		if ((uintptr_t) sig & 15)
+			return fail(PRESS_HIP_EARG, "sig must be 16-byte aligned");
+		a.in = in;
+		a.in_off = in_off;
+		a.in_len = in_len;
+		a.sig = sig;
+		a.off = off;
+		a.nsamp = n;
+		a.out_n = out_n;
+		return launch_depress(method, a, s);
+	}
+
+	uint64_t lo = ~0ull, hi = 0;
+	for (uint32_t r = 0; r < nreads; r++) {
+		if (off[r] & 7)
+			return fail(PRESS_HIP_EARG, "off[%u] is not a multiple of 8 samples", r);
+		if (off[r] + n[r] > total_samples)
+			return fail(PRESS_HIP_EARG, "slot %u ends beyond total_samples", r);
+		lo = in_off[r] < lo ? in_off[r] : lo;
+		hi = in_off[r] + in_len[r] > hi ? in_off[r] + in_len[r] : hi;
+	}
+	if (g.sig.reserve(total_samples * 2 + 64) || g.off.reserve((size_t) nreads * 8) ||
+	    g.nsamp.reserve((size_t) nreads * 4) || g.arena.reserve(hi - lo + 64) || g.arena_off.reserve((size_t) nreads * 8) ||
+	    g.lens2.reserve((size_t) nreads * 8) || g.outn.reserve((size_t) nreads * 4))
+		return PRESS_HIP_EHIP;
+	std::vector<uint64_t> rel(nreads);
+	for (uint32_t r = 0; r < nreads; r++)
+		rel[r] = in_off[r] - lo;
+	HIPCHK(hipMemcpyAsync(g.arena.p, in + lo, hi - lo, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(g.arena_off.p, rel.data(), (size_t) nreads * 8, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(g.lens2.p, in_len, (size_t) nreads * 8, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(g.off.p, off, (size_t) nreads * 8, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(g.nsamp.p, n, (size_t) nreads * 4, hipMemcpyHostToDevice, s));
+	HIPCHK(hipStreamSynchronize(s));
+	a.in = (const uint8_t *) g.arena.p;
+	a.in_off = (const uint64_t *) g.arena_off.p;
+	a.in_len = (const uint64_t *) g.lens2.p;
+	a.sig = (int16_t *) g.sig.p;
+	a.off = (const uint64_t *) g.off.p;
+	a.nsamp = (const uint32_t *) g.nsamp.p;
+	a.out_n = (uint32_t *) g.outn.p;
+	if ((rc = launch_depress(method, a, s)))
+		return rc;
+	HIPCHK(hipMemcpyAsync(out_n, g.outn.p, (size_t) nreads * 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	for (uint32_t r = 0; r < nreads; r++) {
+		if (out_n[r] == UINT32_MAX || out_n[r] == 0)
+			continue;
+		HIPCHK(hipMemcpyAsync(sig + off[r], (int16_t *) g.sig.p + off[r], (size_t) out_n[r] * 2,
+				      hipMemcpyDeviceToHost, s));
+	}
+	HIPCHK(hipStreamSynchronize(s));
+	return 0;
+}
+
+// ------------------------------------------------------------------ huffman.h objects (press/huffman/huffman.h)
+
+namespace {
+
+huffman_node *new_node(bool leaf, unsigned char sym)
+{
+	huffman_node *p = (huffman_node *) calloc(1, sizeof *p);
+	if (!p)
+		return nullptr;
+	p->isLeaf = leaf ? 1 : 0;
+	if (leaf)
+		p->symbol = sym;
+	return p;
+}
+
+// File format (huffman.c:427-439, :549): u32 BE entry count, u32 BE byte count, then per
+// entry {u8 symbol, u8 numbits, ceil(numbits/8) code bytes; bit k of the code at bit k%8
+// of byte k/8, bit 0 next to the root}.
+int parse_table_file(FILE *fp, uint32_t len[256], uint64_t bits[256])
+{
+	unsigned char hd[8];
+	memset(len, 0, 256 * sizeof len[0]);
+	memset(bits, 0, 256 * sizeof bits[0]);
+	if (fread(hd, 1, 8, fp) != 8)
+		return fail(PRESS_HIP_EARG, "Huffman table: short header");
+	uint32_t count = ((uint32_t) hd[0] << 24) | ((uint32_t) hd[1] << 16) | ((uint32_t) hd[2] << 8) | hd[3];
+	if (count > 256)
+		return fail(PRESS_HIP_EARG, "Huffman table: %u entries", count);
+	for (uint32_t i = 0; i < count; i++) {
+		int sym = fgetc(fp), nb = fgetc(fp);
+		if (sym == EOF || nb == EOF || nb == 0 || nb > 64)
+			return fail(PRESS_HIP_EARG, "Huffman table: bad entry %u", i);
+		unsigned char code[8] = { 0 };
+		if (fread(code, 1, (size_t) (nb + 7) / 8, fp) != (size_t) (nb + 7) / 8)
+			return fail(PRESS_HIP_EARG, "Huffman table: truncated");
+		uint64_t b = 0;
+		for (int k = 0; k < nb; k++)
+			if (code[k / 8] & (1u << (k % 8)))
+				b |= 1ull << k;
+		len[sym] = (uint32_t) nb;
+		bits[sym] = b;
+	}
+	return 0;
+}
+
+void collect_codes(const huffman_node *p, uint64_t code, uint32_t depth, uint32_t len[256], uint64_t bits[256])
+{
+	if (!p || depth > 64)
+		return;
+	if (p->isLeaf) {
+		len[p->symbol] = depth;
+		bits[p->symbol] = code;
+		return;
+	}
+	collect_codes(p->zero, code, depth + 1, len, bits);
+	collect_codes(p->one, code | (depth < 64 ? 1ull << depth : 0), depth + 1, len, bits);
+}
+
+int table_from_encoder(SymbolEncoder *se)
+{
+	uint32_t len[256];
+	uint64_t bits[256];
+	if (!se)
+		return fail(PRESS_HIP_EARG, "NULL SymbolEncoder");
+	for (int s = 0; s < 256; s++) {
+		const huffman_code *c = (*se)[s];
+		len[s] = 0;
+		bits[s] = 0;
+		if (!c)
+			continue;
+		len[s] = (uint32_t) c->numbits;
+		for (unsigned long k = 0; k < c->numbits && k < 64; k++)
+			if (c->bits[k / 8] & (1u << (k % 8)))
+				bits[s] |= 1ull << k;
+	}
+	int rc = ctx_init();
+	return rc ? rc : upload_table(len, bits);
+}
+
+int table_from_tree(huffman_node *root)
+{
+	uint32_t len[256];
+	uint64_t bits[256];
+	if (!root)
+		return fail(PRESS_HIP_EARG, "NULL Huffman tree");
+	memset(len, 0, sizeof len);
+	memset(bits, 0, sizeof bits);
+	collect_codes(root, 0, 0, len, bits);
+	int rc = ctx_init();
+	return rc ? rc : upload_table(len, bits);
+}
+
+} // namespace
+
+extern "C" bool read_code_table(FILE *in, huffman_node **rootOut, unsigned int *dataBytesOut)
+{
+	uint32_t len[256];
+	uint64_t bits[256];
+	if (!in || !rootOut)
+		return false;
+	long at = ftell(in);
+	unsigned char hd[8];
+	if (fread(hd, 1, 8, in) != 8)
+		return false;
+	if (dataBytesOut)
+		*dataBytesOut = ((uint32_t) hd[4] << 24) | ((uint32_t) hd[5] << 16) | ((uint32_t) hd[6] << 8) | hd[7];
+	if (fseek(in, at, SEEK_SET) || parse_table_file(in, len, bits))
+		return false;
+	huffman_node *root = new_node(false, 0);
+	if (!root)
+		return false;
+	for (int s = 0; s < 256; s++) {
+		if (!len[s])
+			continue;
+		huffman_node *p = root;
+		for (uint32_t k = 0; k < len[s]; k++) {
+			const bool one = (bits[s] >> k) & 1;
+			if (p->isLeaf) { // a code runs through another one (huffman.c:643)
+				free_huffman_tree(root);
+				return false;
+			}
+			huffman_node **slot = one ? &p->one : &p->zero;
+			if (!*slot) {
+				*slot = new_node(k + 1 == len[s], (unsigned char) s);
+				if (!*slot) {
+					free_huffman_tree(root);
+					return false;
+				}
+				(*slot)->parent = p;
+			}
+			p = *slot;
+		}
+	}
+	*rootOut = root;
+	return true;
+}
+
+extern "C" void build_symbol_encoder(huffman_node *subtree, SymbolEncoder *pSF)
+{
+	if (!subtree || !pSF)
+		return;
+	if (!subtree->isLeaf) {
+		build_symbol_encoder(subtree->zero, pSF);
+		build_symbol_encoder(subtree->one, pSF);
+		return;
+	}
+	// walk up to the root to get the length, then fill the bits from the root down
+	unsigned long nb = 0;
+	for (const huffman_node *p = subtree; p->parent; p = p->parent)
+		nb++;
+	huffman_code *c = (huffman_code *) malloc(sizeof *c);
+	c->numbits = nb;
+	c->bits = (unsigned char *) calloc((nb + 7) / 8 + 1, 1);
+	unsigned long k = nb;
+	for (const huffman_node *p = subtree; p->parent; p = p->parent) {
+		k--;
+		if (p == p->parent->one)
+			c->bits[k / 8] |= (unsigned char) (1u << (k % 8));
+	}
+	(*pSF)[subtree->symbol] = c;
+}
+
+extern "C" void free_encoder(SymbolEncoder *pSE)
+{
+	if (!pSE)
+		return;
+	for (int s = 0; s < 256; s++) {
+		huffman_code *c = (*pSE)[s];
+		if (c) {
+			free(c->bits);
+			free(c);
+		}
+	}
+	free(pSE);
+}
+
+extern "C" void free_huffman_tree(huffman_node *subtree)
+{
+	if (!subtree)
+		return;
+	if (!subtree->isLeaf) {
+		free_huffman_tree(subtree->zero);
+		free_huffman_tree(subtree->one);
+	}
+	free(subtree);
+}
+
+// ------------------------------------------------------------------ drop-in per-read symbols
+
+namespace {
+
+// one read through the batch path; returns 0 and the length, or an error code
+int press_one(int method, const int16_t *in, uint32_t n, uint8_t *out, uint64_t cap, uint64_t *len)
+{
+	const uint64_t off[1] = { 0 };
+	const uint64_t ooff[2] = { 0, cap };
+	uint64_t l = PRESS_HIP_FAILED;
+	if (n == 0)
+		return fail(PRESS_HIP_EARG, "empty read");
+	int rc = press_hip_press_batch(method, in, off, &n, 1, n, out, ooff, &l, 0);
+	if (rc)
+		return rc;
+	if (l == PRESS_HIP_FAILED)
+		return fail(-1, "stream does not fit %llu bytes", (unsigned long long) cap);
+	*len = l;
+	return 0;
+}
+
+int depress_one(int method, const uint8_t *in, uint64_t nbytes, int16_t *out, uint32_t cap, uint32_t *n)
+{
+	const uint64_t off[1] = { 0 };
+	const uint64_t ioff[1] = { 0 };
+	const uint64_t ilen[1] = { nbytes };
+	uint32_t got = UINT32_MAX;
+	if (cap == 0)
+		return fail(PRESS_HIP_EARG, "no room for samples");
+	int rc = press_hip_depress_batch(method, in, ioff, ilen, 1, out, off, &cap, cap, &got, 0);
+	if (rc)
+		return rc;
+	if (got == UINT32_MAX)
+		return fail(-1, "malformed stream");
+	*n = got;
+	return 0;
+}
+
+// exact length of an svb16 / svb32 stream of n values (its callers do not pass it)
+uint64_t svb_stream_len(const uint8_t *in, uint32_t n, bool key2)
+{
+	uint64_t len;
+	if (!key2) {
+		const uint32_t klen = svb16_keylen(n);
+		len = (uint64_t) klen + n;
+		for (uint32_t i = 0; i < n / 8; i++)
+			len += (uint64_t) __builtin_popcount(in[i]);
+		if (n & 7)
+			len += (uint64_t) __builtin_popcount(in[n / 8] & ((1u << (n & 7)) - 1));
+	} else {
+		len = (uint64_t) (n + 3) / 4 + n;
+		for (uint32_t i = 0; i < n; i++)
+			len += (in[i >> 2] >> (2 * (i & 3))) & 3u;
+	}
+	return len;
+}
+
+void void_press(int method, const int16_t *in, uint64_t n, uint8_t *out, uint64_t *nout)
+{
+	uint64_t len = 0;
+	if (press_one(method, in, (uint32_t) n, out, *nout, &len)) {
+		fprintf(stderr, "press_hip: %s\n", g_err);
+		len = 0;
+	}
+	*nout = len;
+}
+
+int int_press_inner(int method, const int16_t *in, uint32_t n, uint8_t *out, uint64_t *nout)
+{
+	uint64_t len = 0;
+	int rc = press_one(method, in, n, out, *nout, &len);
+	if (rc)
+		return -1;
+	*nout = len;
+	return 0;
+}
+
+void void_depress(int method, const uint8_t *in, uint64_t nbytes, int16_t *out, uint32_t *nout)
+{
+	uint32_t n = 0;
+	if (depress_one(method, in, nbytes, out, *nout, &n)) {
+		fprintf(stderr, "press_hip: %s\n", g_err);
+		n = 0;
+	}
+	*nout = n;
+}
+
+// zstd level 1 (press.h:275) around a GPU-made inner stream (press.c:1865, 2025, 8554)
+int zstd_press_(int inner, bool prefix_n, const int16_t *in, uint32_t n, uint8_t *out, uint64_t *nout)
+{
+	if (!zstd_open())
+		return fail(-1, "libzstd not found"), -1;
+	const uint64_t cap = (prefix_n ? 4 : 0) + press_hip_bound(inner, n);
+	std::vector<uint8_t> buf(cap + 64);
+	uint64_t len = 0;
+	if (prefix_n)
+		memcpy(buf.data(), &n, 4);
+	if (press_one(inner, in, n, buf.data() + (prefix_n ? 4 : 0), cap - (prefix_n ? 4 : 0), &len))
+		return -1;
+	len += prefix_n ? 4 : 0;
+	const size_t r = zs.compress(out, *nout, buf.data(), len, 1);
+	if (zs.is_error(r))
+		return -1;
+	*nout = r;
+	return 0;
+}
+
+int zstd_depress_(int inner, bool prefix_n, const uint8_t *in, uint64_t nbytes, int16_t *out, uint32_t *nout)
+{
+	if (!zstd_open())
+		return fail(-1, "libzstd not found"), -1;
+	const uint64_t cap = zstd_bound_((uint64_t) *nout * 2); // press.c:1897
+	std::vector<uint8_t> buf(cap + 64);
+	const size_t r = zs.decompress(buf.data(), cap, in, nbytes);
+	if (zs.is_error(r))
+		return -1;
+	uint32_t n = 0;
+	if (prefix_n) {
+		uint32_t cnt;
+		if (r < 4)
+			return -1;
+		memcpy(&cnt, buf.data(), 4);
+		if (cnt > *nout)
+			return -1;
+		if (cnt && depress_one(inner, buf.data() + 4, r - 4, out, cnt, &n))
+			return -1;
+	} else if (depress_one(inner, buf.data(), r, out, *nout, &n)) {
+		return -1;
+	}
+	*nout = n;
+	return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+uint64_t svb12_bound(uint64_t nin) { return bound_svb16((uint32_t) nin); }
+void svb12_press(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout)
+{
+	void_press(PRESS_HIP_SVB12, in, nin, out, nout);
+}
+void svb12_depress(const uint8_t *in, uint64_t nin, int16_t *out)
+{
+	uint32_t n = (uint32_t) nin;
+	void_depress(PRESS_HIP_SVB12, in, svb_stream_len(in, (uint32_t) nin, false), out, &n);
+}
+
+uint64_t svb12_zd_bound(uint64_t nin) { return bound_svb16((uint32_t) nin); }
+void svb12_zd_press(const int16_t *in, uint64_t nin, uint8_t *out, uint64_t *nout)
+{
+	void_press(PRESS_HIP_SVB12_ZD, in, nin, out, nout);
+}
+void svb12_zd_depress(const uint8_t *in, uint64_t nin, int16_t *out, uint64_t *nout)
+{
+	uint32_t n = (uint32_t) nin;
+	void_depress(PRESS_HIP_SVB12_ZD, in, svb_stream_len(in, (uint32_t) nin, false), out, &n);
+	*nout = n;
+}
+
+uint64_t svb_zd_bound_16(uint64_t nin) { return bound_svb32((uint32_t) nin); }
+void svb_zd_press_16(const int16_t *in, uint64_t nin, uint8_t *out, uint64_t *nout)
+{
+	void_press(PRESS_HIP_SVB_ZD, in, nin, out, nout);
+}
+void svb_zd_depress_16(const uint8_t *in, uint64_t nin, int16_t *out, uint64_t *nout)
+{
+	uint32_t n = (uint32_t) nin;
+	void_depress(PRESS_HIP_SVB_ZD, in, svb_stream_len(in, (uint32_t) nin, true), out, &n);
+	*nout = n;
+}
+
+uint64_t zstd_svb_zd_bound_16(uint32_t nin) { return press_hip_bound(PRESS_HIP_ZSTD_SVB_ZD, nin); }
+int zstd_svb_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout)
+{
+	return zstd_press_(PRESS_HIP_SVB_ZD, true, in, nin, out, nout);
+}
+int zstd_svb_zd_depress_16(const uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout)
+{
+	return zstd_depress_(PRESS_HIP_SVB_ZD, true, in, nin, out, nout);
+}
+
+uint64_t zstd_svb12_zd_bound(uint32_t nin) { return press_hip_bound(PRESS_HIP_ZSTD_SVB12_ZD, nin); }
+int zstd_svb12_zd_press(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout)
+{
+	return zstd_press_(PRESS_HIP_SVB12_ZD, true, in, nin, out, nout);
+}
+int zstd_svb12_zd_depress(const uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout)
+{
+	return zstd_depress_(PRESS_HIP_SVB12_ZD, true, in, nin, out, nout);
+}
+
+#define VB_FAMILY(name, id)                                                                      \
+	uint64_t name##_zd_bound_16(uint32_t nin) { return bound_vbzd(nin); }                    \
+	void name##_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout)   \
+	{                                                                                        \
+		void_press(id, in, nin, out, nout);                                              \
+	}                                                                                        \
+	void name##_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout)       \
+	{                                                                                        \
+		void_depress(id, in, nin, out, nout);                                            \
+	}
+VB_FAMILY(vbe21, PRESS_HIP_VBE21_ZD)
+VB_FAMILY(vbbe21, PRESS_HIP_VBBE21_ZD)
+VB_FAMILY(vbsbe21, PRESS_HIP_VBSBE21_ZD)
+VB_FAMILY(vbsse21, PRESS_HIP_VBSSE21_ZD)
+
+#define SHUFF_FAMILY(name, id)                                                                           \
+	uint64_t shuffman_##name##_zd_bound_16(uint32_t nin) { return bound_vbzd(nin); }                 \
+	int shuffman_##name##_zd_press_16(SymbolEncoder *se, const int16_t *in, uint32_t nin,            \
+					  uint8_t *out, uint64_t *nout)                                  \
+	{                                                                                                \
+		if (table_from_encoder(se))                                                              \
+			return 1;                                                                        \
+		return int_press_inner(id, in, nin, out, nout);                                          \
+	}                                                                                                \
+	int shuffman_##name##_zd_depress_16(huffman_node *root, uint8_t *in, uint64_t nin, int16_t *out, \
+					    uint32_t *nout)                                              \
+	{                                                                                                \
+		if (table_from_tree(root))                                                               \
+			return 1;                                                                        \
+		uint32_t n = 0;                                                                          \
+		if (depress_one(id, in, nin, out, *nout, &n))                                            \
+			return 1;                                                                        \
+		*nout = n;                                                                               \
+		return 0;                                                                                \
+	}
+SHUFF_FAMILY(vbe21, PRESS_HIP_SHUFF_VBE21_ZD)
+SHUFF_FAMILY(vbbe21, PRESS_HIP_SHUFF_VBBE21_ZD)
+SHUFF_FAMILY(vbsbe21, PRESS_HIP_SHUFF_VBSBE21_ZD)
+SHUFF_FAMILY(vbsse21, PRESS_HIP_SHUFF_VBSSE21_ZD)
+
+uint64_t hasgam_vbsse21_zdq_bound_16(uint32_t nin) { return press_hip_bound(PRESS_HIP_HASGAM_ZDQ, nin); }
+int hasgam_vbsse21_zdq_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout)
+{
+	return int_press_inner(PRESS_HIP_HASGAM_ZDQ, in, nin, out, nout);
+}
+int hasgam_vbsse21_zdq_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout)
+{
+	uint32_t n = 0;
+	if (depress_one(PRESS_HIP_HASGAM_ZDQ, in, nin, out, *nout, &n))
+		return -1;
+	*nout = n;
+	return 0;
+}
+
+uint64_t zstd_hasgam_vbsse21_zdq_bound_16(uint32_t nin) { return press_hip_bound(PRESS_HIP_ZSTD_HASGAM_ZDQ, nin); }
+int zstd_hasgam_vbsse21_zdq_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout)
+{
+	return zstd_press_(PRESS_HIP_HASGAM_ZDQ, false, in, nin, out, nout);
+}
+int zstd_hasgam_vbsse21_zdq_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout)
+{
+	return zstd_depress_(PRESS_HIP_HASGAM_ZDQ, false, in, nin, out, nout);
+}
+
+} // extern "C"

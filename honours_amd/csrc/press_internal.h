@@ -1,0 +1,78 @@
+// press_internal.h - shared between the kernels (press_kernels.hip) and the C-ABI
+// host layer (press_abi.hip).  Not installed; the public interface is include/press_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ph {
+
+// Exception-section encodings of the "vb1e2" family (press.c:2679-3405) and ex-zd (ex_zd.c:9).
+enum ExFmt : int {
+	EXF_VBE21 = 0,   // nex x u32 pos, nex x u16 raw value
+	EXF_VBBE21 = 1,  // bit-packed position deltas, bit-packed (value-256)
+	EXF_VBSBE21 = 2, // svb32 position deltas, bit-packed (value-256)
+	EXF_VBSSE21 = 3, // svb32 position deltas, svb16 (value-256)
+	EXF_EXZD = 4     // svb32 position deltas, svb32 (value-256); one exception = 2 x u32
+};
+
+// Per-read record shared by the passes of the exception-split methods (device memory).
+struct ReadMeta {
+	uint32_t nex;     // exceptions among zd[1..n)
+	uint32_t ored;    // OR of all samples (ex-zd qts, ex_zd.c:358-381)
+	uint32_t zd0;     // zd[0], stored raw in the header
+	uint32_t q;       // ex-zd shift (0 for the other methods)
+	uint32_t hdr;     // bytes in front of the "u32 nex" field: 2, or 12 for ex-zd
+	uint32_t seclen;  // bytes of "u32 nex || exception section"
+	uint32_t nlow;    // one-byte values in the stream (decode side)
+	uint32_t status;  // 0 = ok, anything else = this read failed
+};
+
+// Static-Huffman tables on the device (built on the host from the 256 {len,bits} pairs).
+constexpr int HUF_LUT_BITS = 12;
+struct HuffDev {
+	uint32_t enc[256];                 // code bits (bit k = k-th emitted bit) | len << 24
+	uint16_t lut[1 << HUF_LUT_BITS];   // sym | len << 8 for codes <= 12 bits, 0xFFFF: walk the trie
+	int16_t child[1024][2];            // binary trie, node 0 = root, -1 = none
+	int16_t leaf[1024];                // symbol at a leaf, -1 otherwise
+};
+
+// Arguments common to every batch kernel.
+struct BatchArgs {
+	const int16_t *sig;       // samples of all reads
+	const uint64_t *off;      // [nreads] read r starts at sig[off[r]] (multiple of 8 samples)
+	const uint32_t *nsamp;    // [nreads] samples in read r
+	uint8_t *out;             // compressed arena
+	const uint64_t *out_off;  // [nreads+1] slot of read r
+	uint64_t *out_len;        // [nreads] bytes produced / UINT64_MAX
+	ReadMeta *meta;           // [nreads]
+	uint32_t *ex_pos;         // [total samples] exception positions of read r at ex_pos[off[r]..]
+	uint32_t *ex_val;         // [total samples] raw exception values
+	const HuffDev *huff;
+	uint32_t nreads;
+};
+
+struct DecodeArgs {
+	const uint8_t *in;        // compressed arena
+	const uint64_t *in_off;   // [nreads]
+	const uint64_t *in_len;   // [nreads]
+	int16_t *sig;             // decoded samples
+	const uint64_t *off;      // [nreads] slot of read r starts at sig[off[r]] (multiple of 8 samples)
+	const uint32_t *nsamp;    // [nreads] slot capacity in samples (= the sample count for svb streams)
+	uint32_t *out_n;          // [nreads] samples decoded / UINT32_MAX
+	ReadMeta *meta;
+	uint32_t *ex_pos;
+	uint32_t *ex_val;
+	uint8_t *low;             // [total samples] Huffman-decoded one-byte stream of read r at low[off[r]..]
+	const HuffDev *huff;
+	uint32_t nreads;
+};
+
+// launchers (press_kernels.hip).  All asynchronous on `s`.
+void launch_svb_encode(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s);
+void launch_svb_decode(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s);
+// exception-split encode: scan (+ qts redo for ex-zd) -> section -> one-byte / Huffman stream
+void launch_ex_encode(const BatchArgs &a, int fmt, bool huff, hipStream_t s);
+void launch_ex_decode(const DecodeArgs &a, int fmt, bool huff, hipStream_t s);
+
+} // namespace ph

@@ -1,0 +1,343 @@
+"""Host-side mirror of the reference's per-method interface (press/press.h) over
+libpress_hip.so, plus the batch entry points.
+
+Per-read calls go through the DROP-IN C symbols (``svb12_zd_press`` ...) exactly as
+press/test.c's ``test_X`` functions call them (test.c:1756-1815): bound -> press ->
+depress.  Batch calls take torch CUDA tensors (device memory plumbing only) and enqueue
+on torch's current stream.
+
+No fallback: if the library is missing or no GPU is present, calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpress_hip.so")
+TABLE_PATH = os.path.join(_HERE, "data", "NA12878_zd.huffman")
+
+# include/press_hip.h enum press_hip_method
+METHODS = {
+    "svb12": 0, "svb12_zd": 1, "svb_zd": 2, "zstd_svb_zd": 3, "zstd_svb12_zd": 4,
+    "vbe21_zd": 5, "vbbe21_zd": 6, "vbsbe21_zd": 7, "vbsse21_zd": 8,
+    "shuffman_vbe21_zd": 9, "shuffman_vbbe21_zd": 10, "shuffman_vbsbe21_zd": 11,
+    "shuffman_vbsse21_zd": 12, "hasgam_vbsse21_zdq": 13, "zstd_hasgam_vbsse21_zdq": 14,
+}
+BATCH_METHODS = [m for m in METHODS if not m.startswith("zstd_")]
+FAILED = (1 << 64) - 1
+
+# method -> (bound symbol, press symbol, depress symbol, calling convention)
+#   "svb"    void press(in, n, out, &nout64);  void depress(in, nsamples, out, &nout64)
+#   "svb_nz" as svb, depress without nout (svb12_depress)
+#   "vb"     void press(in, n32, out, &nout64); void depress(in, nbytes, out, &nout32)
+#   "int"    int press(...) ; int depress(in, nbytes, out, &nout32)
+#   "shuff"  int press(se, ...); int depress(root, ...)
+_SYMS = {
+    "svb12": ("svb12_bound", "svb12_press", "svb12_depress", "svb_nz"),
+    "svb12_zd": ("svb12_zd_bound", "svb12_zd_press", "svb12_zd_depress", "svb"),
+    "svb_zd": ("svb_zd_bound_16", "svb_zd_press_16", "svb_zd_depress_16", "svb"),
+    "zstd_svb_zd": ("zstd_svb_zd_bound_16", "zstd_svb_zd_press_16", "zstd_svb_zd_depress_16", "int"),
+    "zstd_svb12_zd": ("zstd_svb12_zd_bound", "zstd_svb12_zd_press", "zstd_svb12_zd_depress", "int"),
+    "vbe21_zd": ("vbe21_zd_bound_16", "vbe21_zd_press_16", "vbe21_zd_depress_16", "vb"),
+    "vbbe21_zd": ("vbbe21_zd_bound_16", "vbbe21_zd_press_16", "vbbe21_zd_depress_16", "vb"),
+    "vbsbe21_zd": ("vbsbe21_zd_bound_16", "vbsbe21_zd_press_16", "vbsbe21_zd_depress_16", "vb"),
+    "vbsse21_zd": ("vbsse21_zd_bound_16", "vbsse21_zd_press_16", "vbsse21_zd_depress_16", "vb"),
+    "shuffman_vbe21_zd": ("shuffman_vbe21_zd_bound_16", "shuffman_vbe21_zd_press_16",
+                          "shuffman_vbe21_zd_depress_16", "shuff"),
+    "shuffman_vbbe21_zd": ("shuffman_vbbe21_zd_bound_16", "shuffman_vbbe21_zd_press_16",
+                           "shuffman_vbbe21_zd_depress_16", "shuff"),
+    "shuffman_vbsbe21_zd": ("shuffman_vbsbe21_zd_bound_16", "shuffman_vbsbe21_zd_press_16",
+                            "shuffman_vbsbe21_zd_depress_16", "shuff"),
+    "shuffman_vbsse21_zd": ("shuffman_vbsse21_zd_bound_16", "shuffman_vbsse21_zd_press_16",
+                            "shuffman_vbsse21_zd_depress_16", "shuff"),
+    "hasgam_vbsse21_zdq": ("hasgam_vbsse21_zdq_bound_16", "hasgam_vbsse21_zdq_press_16",
+                           "hasgam_vbsse21_zdq_depress_16", "int"),
+    "zstd_hasgam_vbsse21_zdq": ("zstd_hasgam_vbsse21_zdq_bound_16", "zstd_hasgam_vbsse21_zdq_press_16",
+                                "zstd_hasgam_vbsse21_zdq_depress_16", "int"),
+}
+
+# every symbol include/press_hip.h declares (checked by tests/test_abi_symbols.py)
+HEADER_SYMBOLS = sorted(set(
+    [s for t in _SYMS.values() for s in t[:3]] +
+    ["read_code_table", "build_symbol_encoder", "free_encoder", "free_huffman_tree",
+     "press_hip_last_error", "press_hip_set_device", "press_hip_set_stream", "press_hip_get_stream",
+     "press_hip_synchronize", "press_hip_load_table_file", "press_hip_set_table", "press_hip_bound",
+     "press_hip_press_batch", "press_hip_depress_batch", "press_hip_workspace_bytes",
+     "press_hip_shutdown"]))
+
+
+class PressError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=LIB_PATH):
+    """dlopen libpress_hip.so (no GPU needed for that) - raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(path):
+            raise PressError("%s is not built: run `python -m honours_amd.build` "
+                             "(there is no CPU fallback)" % path)
+        _lib = ctypes.CDLL(path)
+        _lib.press_hip_last_error.restype = ctypes.c_char_p
+        _lib.press_hip_bound.restype = ctypes.c_uint64
+        _lib.press_hip_bound.argtypes = [ctypes.c_int, ctypes.c_uint32]
+        _lib.press_hip_workspace_bytes.restype = ctypes.c_uint64
+        _lib.press_hip_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32]
+        _lib.press_hip_get_stream.restype = ctypes.c_void_p
+        _lib.press_hip_set_stream.argtypes = [ctypes.c_void_p]
+        _lib.press_hip_load_table_file.argtypes = [ctypes.c_char_p]
+        _lib.press_hip_press_batch.restype = ctypes.c_int
+        _lib.press_hip_press_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        _lib.press_hip_depress_batch.restype = ctypes.c_int
+        _lib.press_hip_depress_batch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                                 ctypes.c_int]
+        libc = ctypes.CDLL(None)
+        libc.fopen.restype = ctypes.c_void_p
+        libc.fopen.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        libc.fclose.argtypes = [ctypes.c_void_p]
+        libc.malloc.restype = ctypes.c_void_p
+        libc.malloc.argtypes = [ctypes.c_size_t]
+        _lib._libc = libc
+        _lib.read_code_table.restype = ctypes.c_bool
+        _lib.read_code_table.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p),
+                                         ctypes.POINTER(ctypes.c_uint)]
+        _lib.build_symbol_encoder.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _lib.free_encoder.argtypes = [ctypes.c_void_p]
+        _lib.free_huffman_tree.argtypes = [ctypes.c_void_p]
+    return _lib
+
+
+def last_error():
+    return load_library().press_hip_last_error().decode()
+
+
+def _mid(method):
+    return METHODS[method] if isinstance(method, str) else int(method)
+
+
+class HuffmanTable:
+    """The caller-owned table objects of press/test.c:3786-3791: read_code_table on the
+    table file, then build_symbol_encoder into a malloc'd SymbolEncoder."""
+
+    def __init__(self, path=TABLE_PATH):
+        lib = load_library()
+        fp = lib._libc.fopen(path.encode(), b"r")
+        if not fp:
+            raise PressError("cannot open " + path)
+        self.root = ctypes.c_void_p()
+        nbytes = ctypes.c_uint()
+        ok = lib.read_code_table(fp, ctypes.byref(self.root), ctypes.byref(nbytes))
+        lib._libc.fclose(fp)
+        if not ok:
+            raise PressError("read_code_table failed on " + path)
+        self.se = lib._libc.malloc(256 * ctypes.sizeof(ctypes.c_void_p))
+        ctypes.memset(self.se, 0, 256 * ctypes.sizeof(ctypes.c_void_p))
+        lib.build_symbol_encoder(self.root, self.se)
+
+    def close(self):
+        lib = load_library()
+        if self.se:
+            lib.free_encoder(self.se)
+            self.se = None
+        if self.root:
+            lib.free_huffman_tree(self.root)
+            self.root = None
+
+
+_table = None
+
+
+def default_table():
+    global _table
+    if _table is None:
+        _table = HuffmanTable()
+    return _table
+
+
+def bound(method, n):
+    """X_bound(n): what press/test.c mallocs for the compressed read."""
+    lib = load_library()
+    name = _SYMS[method][0]
+    fn = getattr(lib, name)
+    fn.restype = ctypes.c_uint64
+    fn.argtypes = [ctypes.c_uint64 if _SYMS[method][3] in ("svb", "svb_nz") else ctypes.c_uint32]
+    return int(fn(n))
+
+
+def press(method, sig, cap=None):
+    """X_press through the drop-in symbol. -> (ret, bytes); ret as the reference returns it
+    (void methods: 0, or -1 when the library reports *nout = 0)."""
+    lib = load_library()
+    _, pname, _, kind = _SYMS[method]
+    sig = np.ascontiguousarray(sig, dtype=np.int16)
+    n = sig.size
+    cap = bound(method, n) + 1024 if cap is None else int(cap)
+    out = np.zeros(cap + 64, dtype=np.uint8)
+    out[cap:] = 0xA5  # canary: nothing may be written past the capacity
+    nout = ctypes.c_uint64(cap)
+    fn = getattr(lib, pname)
+    if kind in ("svb", "svb_nz", "vb"):
+        fn.restype = None
+        nt = ctypes.c_uint32 if (kind == "vb" or method == "svb12") else ctypes.c_uint64
+        fn.argtypes = [ctypes.c_void_p, nt, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        fn(sig.ctypes.data, n, out.ctypes.data, ctypes.byref(nout))
+        ret = 0 if nout.value else -1
+    elif kind == "int":
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        ret = fn(sig.ctypes.data, n, out.ctypes.data, ctypes.byref(nout))
+    else:
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                       ctypes.POINTER(ctypes.c_uint64)]
+        ret = fn(default_table().se, sig.ctypes.data, n, out.ctypes.data, ctypes.byref(nout))
+    if not np.all(out[cap:] == 0xA5):
+        raise PressError("%s wrote past its capacity" % pname)
+    return ret, (out[: nout.value].tobytes() if ret == 0 else b"")
+
+
+def depress(method, comp, n):
+    """X_depress through the drop-in symbol. -> (ret, int16 array)"""
+    lib = load_library()
+    _, _, dname, kind = _SYMS[method]
+    buf = np.frombuffer(bytes(comp) + b"\0" * 64, dtype=np.uint8).copy()
+    out = np.zeros(n + 64, dtype=np.int16)
+    out[n:] = 0x5A5A
+    fn = getattr(lib, dname)
+    ret = 0
+    if kind == "svb_nz":
+        fn.restype = None
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        fn(buf.ctypes.data, n, out.ctypes.data)
+        got = n
+    elif kind == "svb":
+        fn.restype = None
+        nout = ctypes.c_uint64(n)
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        fn(buf.ctypes.data, n, out.ctypes.data, ctypes.byref(nout))
+        got = nout.value
+    else:
+        nout = ctypes.c_uint32(n)
+        if kind == "shuff":
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                           ctypes.POINTER(ctypes.c_uint32)]
+            ret = fn(default_table().root, buf.ctypes.data, len(comp), out.ctypes.data, ctypes.byref(nout))
+        else:
+            fn.restype = None if kind == "vb" else ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+            r = fn(buf.ctypes.data, len(comp), out.ctypes.data, ctypes.byref(nout))
+            ret = 0 if kind == "vb" else r
+        got = nout.value
+        if kind == "vb" and got == 0:
+            ret = -1
+    if not np.all(out[n:] == 0x5A5A):
+        raise PressError("%s wrote past the sample capacity" % dname)
+    return ret, out[:got].copy()
+
+
+# ---------------------------------------------------------------------------- batch API (torch CUDA tensors)
+
+def use_torch_stream():
+    """Make the batch calls enqueue on torch's current CUDA stream."""
+    import torch
+
+    lib = load_library()
+    rc = lib.press_hip_set_device(torch.cuda.current_device())
+    if rc:
+        raise PressError(last_error())
+    rc = lib.press_hip_set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc:
+        raise PressError(last_error())
+
+
+def load_table(path=TABLE_PATH):
+    lib = load_library()
+    if lib.press_hip_load_table_file(path.encode()):
+        raise PressError(last_error())
+
+
+def press_batch(method, sig, off, n, out, out_off, out_len):
+    """Enqueue the compression of a batch.  All arguments are CUDA tensors: sig int16,
+    off int64 (nreads read starts, multiples of 8), n int32 (nreads sample counts),
+    out uint8, out_off int64 (nreads+1 slot bounds), out_len int64 (nreads; -1 = failed)."""
+    lib = load_library()
+    nreads = off.numel()
+    rc = lib.press_hip_press_batch(_mid(method), sig.data_ptr(), off.data_ptr(), n.data_ptr(), nreads,
+                                   sig.numel(), out.data_ptr(), out_off.data_ptr(), out_len.data_ptr(), 1)
+    if rc:
+        raise PressError(last_error())
+
+
+def depress_batch(method, comp, in_off, in_len, sig, off, n, out_n):
+    """Enqueue the decompression of a batch (CUDA tensors; out_n int32, -1 = failed)."""
+    lib = load_library()
+    nreads = off.numel()
+    rc = lib.press_hip_depress_batch(_mid(method), comp.data_ptr(), in_off.data_ptr(), in_len.data_ptr(),
+                                     nreads, sig.data_ptr(), off.data_ptr(), n.data_ptr(), sig.numel(),
+                                     out_n.data_ptr(), 1)
+    if rc:
+        raise PressError(last_error())
+
+
+def _layout(ns):
+    """read starts padded to multiples of 8 samples -> (off uint64[nreads], total)"""
+    ns = np.asarray(ns, dtype=np.int64)
+    pad = (ns + 7) // 8 * 8
+    off = np.zeros(ns.size, dtype=np.uint64)
+    if ns.size > 1:
+        off[1:] = np.cumsum(pad)[:-1]
+    return off, int(pad.sum())
+
+
+def press_batch_host(method, reads, caps=None):
+    """Batch call with host buffers: reads = list of int16 arrays -> list of bytes / None."""
+    lib = load_library()
+    nreads = len(reads)
+    ns = np.array([len(r) for r in reads], dtype=np.uint32)
+    off, total = _layout(ns)
+    sig = np.zeros(total + 64, dtype=np.int16)
+    for r, o in zip(reads, off):
+        sig[int(o): int(o) + len(r)] = r
+    if caps is None:
+        caps = [int(lib.press_hip_bound(_mid(method), int(x))) + 1024 for x in ns]
+    out_off = np.zeros(nreads + 1, dtype=np.uint64)
+    out_off[1:] = np.cumsum((np.asarray(caps, dtype=np.uint64) + 15) // 16 * 16)
+    out = np.zeros(int(out_off[-1]) + 64, dtype=np.uint8)
+    out_len = np.zeros(nreads, dtype=np.uint64)
+    rc = lib.press_hip_press_batch(_mid(method), sig.ctypes.data, off.ctypes.data, ns.ctypes.data, nreads,
+                                   total, out.ctypes.data, out_off.ctypes.data, out_len.ctypes.data, 0)
+    if rc:
+        raise PressError(last_error())
+    return [None if int(l) == FAILED else out[int(o): int(o) + int(l)].tobytes()
+            for o, l in zip(out_off[:-1], out_len)]
+
+
+def depress_batch_host(method, streams, ns):
+    """Batch decode with host buffers: streams = list of bytes, ns = sample counts / capacities."""
+    lib = load_library()
+    nreads = len(streams)
+    in_len = np.array([len(s) for s in streams], dtype=np.uint64)
+    in_off = np.zeros(nreads, dtype=np.uint64)
+    if nreads > 1:
+        in_off[1:] = np.cumsum(in_len)[:-1]
+    comp = np.frombuffer(b"".join(streams) + b"\0" * 64, dtype=np.uint8).copy()
+    ns = np.asarray(ns, dtype=np.uint32)
+    off, total = _layout(ns)
+    sig = np.zeros(total + 64, dtype=np.int16)
+    out_n = np.zeros(nreads, dtype=np.uint32)
+    rc = lib.press_hip_depress_batch(_mid(method), comp.ctypes.data, in_off.ctypes.data, in_len.ctypes.data,
+                                     nreads, sig.ctypes.data, off.ctypes.data, ns.ctypes.data, total,
+                                     out_n.ctypes.data, 0)
+    if rc:
+        raise PressError(last_error())
+    return [None if int(k) == 0xFFFFFFFF else sig[int(o): int(o) + int(k)].copy()
+            for o, k in zip(off, out_n)]

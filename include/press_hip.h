@@ -1,0 +1,228 @@
+/*
+ * press_hip.h - C ABI of libpress_hip.so: the MI355X (gfx950) implementation of the
+ * per-read transform -> pack -> entropy hot path of sashajenner/honours `press/`.
+ *
+ * Two groups of entry points:
+ *
+ *  (1) DROP-IN SYMBOLS.  Exactly the X_bound / X_press / X_depress triples that
+ *      press/press.h declares for the hot-path methods (file:line cited on each),
+ *      plus the four huffman.h functions press/test.c calls for the static table.
+ *      Same names, prototypes, argument meaning and return codes, so the
+ *      reference's unmodified harness (press/test.c, TEST() in press/test.h:10-37)
+ *      links against this library for these methods.  Host pointers in, host
+ *      pointers out; each call is H2D copy -> kernels -> D2H copy on a private
+ *      stream, synchronous like the reference.
+ *
+ *  (2) BATCH API (press_hip_*).  Not in the reference: one call per batch of reads
+ *      with device-resident buffers - the throughput path (one read per call is
+ *      launch/PCIe-latency bound).  Reads are independent (thesis/probspace/
+ *      focus.tex:177-183), so a batch is the natural device unit.
+ *
+ * Plain C: pointers and sizes only, no C++ or torch types.
+ * Deviation from the reference, on purpose: X_press never writes past the capacity
+ * passed in *nout (the reference ignores it and relies on X_bound being large
+ * enough, press/test.c:1788).  When the stream does not fit, int methods return -1
+ * and void methods set *nout = 0.
+ */
+#ifndef PRESS_HIP_H
+#define PRESS_HIP_H
+
+#include <stdbool.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ======================================================================= (1) drop-in symbols */
+
+/* ---- static Huffman table objects: press/huffman/huffman.h:22-51 (layout kept) ---- */
+#ifndef HUFFMAN_HUFFMAN_H
+#define MAX_SYMBOLS 256
+typedef struct huffman_node_tag {
+	unsigned char isLeaf;
+	unsigned long count;
+	struct huffman_node_tag *parent;
+	union {
+		struct {
+			struct huffman_node_tag *zero, *one;
+		};
+		unsigned char symbol;
+	};
+} huffman_node;
+typedef struct huffman_code_tag {
+	unsigned long numbits; /* code length in bits */
+	unsigned char *bits;   /* bit k of the code at bit k%8 of bits[k/8]; bit 0 is emitted first */
+} huffman_code;
+typedef huffman_code *SymbolEncoder[MAX_SYMBOLS];
+#endif
+
+/* huffman.h:58 / huffman.c:549 - parse the table file (format: SURVEY.md 8(a) a10) */
+bool read_code_table(FILE *in, huffman_node **rootOut, unsigned int *dataBytesOut);
+/* huffman.h:65 / huffman.c:353 */
+void build_symbol_encoder(huffman_node *subtree, SymbolEncoder *pSF);
+/* huffman.h:66 / huffman.c:145 - frees the codes AND *pSE itself, as the reference does */
+void free_encoder(SymbolEncoder *pSE);
+/* huffman.h:67 / huffman.c:117 */
+void free_huffman_tree(huffman_node *subtree);
+
+/* ---- svb16 without zd: press.h:317-320 (press.c:1568-1581) ---- */
+uint64_t svb12_bound(uint64_t nin);
+void svb12_press(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+void svb12_depress(const uint8_t *in, uint64_t nin /* samples */, int16_t *out);
+
+/* ---- svb16-zd: press.h:348-352 (press.c:1678-1694).  nin of depress = samples ---- */
+uint64_t svb12_zd_bound(uint64_t nin);
+void svb12_zd_press(const int16_t *in, uint64_t nin, uint8_t *out, uint64_t *nout);
+void svb12_zd_depress(const uint8_t *in, uint64_t nin, int16_t *out, uint64_t *nout);
+
+/* ---- svb-zd (svb32): press.h:324-328 (press.c:1585-1611) ---- */
+uint64_t svb_zd_bound_16(uint64_t nin);
+void svb_zd_press_16(const int16_t *in, uint64_t nin, uint8_t *out, uint64_t *nout);
+void svb_zd_depress_16(const uint8_t *in, uint64_t nin, int16_t *out, uint64_t *nout);
+
+/* ---- VBZ = zstd-svb-zd: press.h:380-384 (press.c:1860-1910).  The inner stream is
+ * produced on the GPU; the zstd stage is the third-party libzstd the reference itself
+ * calls (press.c:1464), loaded at run time.  -1 when libzstd is not present. ---- */
+uint64_t zstd_svb_zd_bound_16(uint32_t nin);
+int zstd_svb_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+int zstd_svb_zd_depress_16(const uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+
+/* ---- zstd-svb16-zd: press.h:404-408 (press.c:2020-2070) ---- */
+uint64_t zstd_svb12_zd_bound(uint32_t nin);
+int zstd_svb12_zd_press(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+int zstd_svb12_zd_depress(const uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+
+/* ---- exception split: press.h:498-526 (press.c:3411-3580 over :2679-3405).
+ * depress: nin = compressed bytes; *nout = decoded samples ---- */
+uint64_t vbe21_zd_bound_16(uint32_t nin);
+void vbe21_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+void vbe21_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+uint64_t vbbe21_zd_bound_16(uint32_t nin);
+void vbbe21_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+void vbbe21_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+uint64_t vbsbe21_zd_bound_16(uint32_t nin);
+void vbsbe21_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+void vbsbe21_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+uint64_t vbsse21_zd_bound_16(uint32_t nin);
+void vbsse21_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+void vbsse21_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+
+/* ---- static Huffman over the one-byte stream: press.h:634-662 (press.c:4409-4846).
+ * se / root are the caller's table objects (read_code_table / build_symbol_encoder);
+ * their codes are flattened and uploaded to the device (cached by content).
+ * press returns 0 ok, -1 capacity, 1 Huffman-layer failure (as huffman.c does). ---- */
+uint64_t shuffman_vbe21_zd_bound_16(uint32_t nin);
+int shuffman_vbe21_zd_press_16(SymbolEncoder *se, const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+int shuffman_vbe21_zd_depress_16(huffman_node *root, uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+uint64_t shuffman_vbbe21_zd_bound_16(uint32_t nin);
+int shuffman_vbbe21_zd_press_16(SymbolEncoder *se, const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+int shuffman_vbbe21_zd_depress_16(huffman_node *root, uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+uint64_t shuffman_vbsbe21_zd_bound_16(uint32_t nin);
+int shuffman_vbsbe21_zd_press_16(SymbolEncoder *se, const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+int shuffman_vbsbe21_zd_depress_16(huffman_node *root, uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+uint64_t shuffman_vbsse21_zd_bound_16(uint32_t nin);
+int shuffman_vbsse21_zd_press_16(SymbolEncoder *se, const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+int shuffman_vbsse21_zd_depress_16(huffman_node *root, uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+
+/* ---- ex-zd v0: press.h:960-964 (press.c:8461-8500 over ex_zd.c:403,495) ---- */
+uint64_t hasgam_vbsse21_zdq_bound_16(uint32_t nin);
+int hasgam_vbsse21_zdq_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+int hasgam_vbsse21_zdq_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+
+/* ---- zstd over ex-zd: press.h:976-980 (press.c:8549-8589) ---- */
+uint64_t zstd_hasgam_vbsse21_zdq_bound_16(uint32_t nin);
+int zstd_hasgam_vbsse21_zdq_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+int zstd_hasgam_vbsse21_zdq_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+
+/* ======================================================================= (2) batch API */
+
+/* method ids (== oracle/press_methods.h); names are the reference's code names */
+enum press_hip_method {
+	PRESS_HIP_SVB12            = 0,
+	PRESS_HIP_SVB12_ZD         = 1,
+	PRESS_HIP_SVB_ZD           = 2,
+	PRESS_HIP_ZSTD_SVB_ZD      = 3,  /* per-read API only (host zstd stage) */
+	PRESS_HIP_ZSTD_SVB12_ZD    = 4,  /* per-read API only */
+	PRESS_HIP_VBE21_ZD         = 5,
+	PRESS_HIP_VBBE21_ZD        = 6,
+	PRESS_HIP_VBSBE21_ZD       = 7,
+	PRESS_HIP_VBSSE21_ZD       = 8,
+	PRESS_HIP_SHUFF_VBE21_ZD   = 9,
+	PRESS_HIP_SHUFF_VBBE21_ZD  = 10,
+	PRESS_HIP_SHUFF_VBSBE21_ZD = 11,
+	PRESS_HIP_SHUFF_VBSSE21_ZD = 12,
+	PRESS_HIP_HASGAM_ZDQ       = 13,
+	PRESS_HIP_ZSTD_HASGAM_ZDQ  = 14, /* per-read API only */
+	PRESS_HIP_NMETHODS         = 15
+};
+
+#define PRESS_HIP_OK        0
+#define PRESS_HIP_EARG     (-2)  /* bad argument (method, alignment, NULL) */
+#define PRESS_HIP_EHIP     (-3)  /* a HIP runtime call failed */
+#define PRESS_HIP_ENOTABLE (-4)  /* static-Huffman method without a table */
+#define PRESS_HIP_FAILED   UINT64_MAX /* per-read length on failure (capacity, malformed stream) */
+
+/* last HIP / library error as text (thread local) */
+const char *press_hip_last_error(void);
+
+/* select the device for this process (default: current device).  One process per GPU. */
+int press_hip_set_device(int device);
+/* stream (hipStream_t, as void*) the batch calls enqueue on; NULL = library's own */
+int press_hip_set_stream(void *stream);
+void *press_hip_get_stream(void);
+/* block until everything enqueued by batch calls has finished */
+int press_hip_synchronize(void);
+
+/* static Huffman table for the batch API: file in the format of press/NA12878_zd.huffman */
+int press_hip_load_table_file(const char *path);
+/* or 256 {length, code bits} pairs; bit k of bits[s] is the k-th emitted bit */
+int press_hip_set_table(const uint32_t len[256], const uint64_t bits[256]);
+
+/* X_bound of the reference for `method` (what press/test.c allocates) */
+uint64_t press_hip_bound(int method, uint32_t n);
+
+/*
+ * Compress nreads reads.
+ *   sig      int16 samples; read r = sig[off[r] .. off[r]+n[r]).  off (nreads entries)
+ *            must be multiples of 8 samples and sig 16-byte aligned: every sample load
+ *            is a coalesced 16-byte access
+ *   n        samples per read (nreads entries)
+ *   total_samples  extent of sig in samples: max(off[r]+n[r]) rounded up as the caller
+ *            likes; sizes the library's scratch (with device-resident offsets the
+ *            library cannot read them without a synchronisation)
+ *   out      output arena; read r may use out[out_off[r] .. out_off[r+1]) - its
+ *            capacity; out_off has nreads+1 entries
+ *   out_len  per read: bytes produced, or PRESS_HIP_FAILED (capacity too small, ...)
+ * device_resident != 0: every pointer is a device pointer, the call only enqueues
+ * work on the current stream (no synchronisation; scratch is (re)allocated only when a
+ * batch is larger than any before it); == 0: host pointers, synchronous.
+ */
+int press_hip_press_batch(int method, const int16_t *sig, const uint64_t *off, const uint32_t *n,
+			  uint32_t nreads, uint64_t total_samples, uint8_t *out,
+			  const uint64_t *out_off, uint64_t *out_len, int device_resident);
+
+/*
+ * Decompress nreads streams.
+ *   in/in_off/in_len  stream r = in[in_off[r] .. in_off[r]+in_len[r])
+ *   sig/off/n         output layout as above; n[r] is the room for read r in samples
+ *                     AND, for the svb methods, the sample count (their streams do
+ *                     not carry it, press.c:1689)
+ *   out_n             per read: samples decoded, or UINT32_MAX on a malformed stream
+ */
+int press_hip_depress_batch(int method, const uint8_t *in, const uint64_t *in_off,
+			    const uint64_t *in_len, uint32_t nreads, int16_t *sig,
+			    const uint64_t *off, const uint32_t *n, uint64_t total_samples,
+			    uint32_t *out_n, int device_resident);
+
+/* bytes of device scratch the two calls above keep for a batch of this shape (informational) */
+uint64_t press_hip_workspace_bytes(int method, uint64_t total_samples, uint32_t nreads);
+
+/* release every device and host resource held by the library */
+void press_hip_shutdown(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRESS_HIP_H */

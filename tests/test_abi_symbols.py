@@ -1,0 +1,74 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/press_hip.h declares.  No compute calls (no GPU here)."""
+import os
+import re
+
+import pytest
+
+from honours_amd import build, press
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()
+    return press.load_library()
+
+
+def _declared_symbols():
+    """function names declared in include/press_hip.h (incl. the macro-free drop-in list)"""
+    src = open(os.path.join(ROOT, "include", "press_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", src))
+    return {n for n in names if n not in ("defined",)}
+
+
+def test_header_symbols_exported(lib):
+    decl = _declared_symbols()
+    assert len(decl) >= 60
+    missing = [s for s in sorted(decl) if not hasattr(lib, s)]
+    assert not missing, missing
+    # and the python mirror knows the same list
+    assert set(press.HEADER_SYMBOLS) == decl
+
+
+def test_bounds_match_oracle(lib, oracle):
+    """X_bound is host arithmetic: same values as the oracle"""
+    for m in press.METHODS:
+        for n in (1, 2, 7, 8, 9, 1000, 7329, 155185, 200000, 5724000):
+            assert press.bound(m, n) == oracle.bound(m, n), (m, n)
+            assert lib.press_hip_bound(press.METHODS[m], n) == oracle.bound(m, n), (m, n)
+
+
+def test_huffman_objects_roundtrip(lib, oracle):
+    """read_code_table + build_symbol_encoder (press/test.c:3786-3791) reproduce the codes"""
+    import ctypes
+
+    t = press.HuffmanTable()
+    want = oracle.table()
+    se = ctypes.cast(t.se, ctypes.POINTER(ctypes.c_void_p * 256)).contents
+
+    class Code(ctypes.Structure):
+        _fields_ = [("numbits", ctypes.c_ulong), ("bits", ctypes.POINTER(ctypes.c_ubyte))]
+
+    for s in range(256):
+        c = ctypes.cast(se[s], ctypes.POINTER(Code)).contents
+        bits = 0
+        for k in range(c.numbits):
+            if c.bits[k // 8] & (1 << (k % 8)):
+                bits |= 1 << k
+        assert (c.numbits, bits) == want[s], s
+    t.close()
+
+
+def test_no_gpu_fails_loudly(lib):
+    """without a device the product path reports an error - it never falls back to the CPU"""
+    import numpy as np
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ret, out = press.press("hasgam_vbsse21_zdq", np.arange(100, dtype=np.int16))
+    assert ret != 0 and out == b""
+    assert "HIP" in press.last_error() or "hip" in press.last_error()
