@@ -249,8 +249,18 @@ extern "C" int press_hip_set_stream(void *stream)
 	int rc = ctx_init();
 	if (rc)
 		return rc;
-	g.user = (hipStream_t) stream;
-	g.use_user = stream != nullptr;
+	g.user = (hipStream_t) stream; // nullptr = the default (null) stream
+	g.use_user = true;
+	return 0;
+}
+
+extern "C" int press_hip_reset_stream(void)
+{
+	int rc = ctx_init();
+	if (rc)
+		return rc;
+	g.user = nullptr;
+	g.use_user = false;
 	return 0;
 }
 

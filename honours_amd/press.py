@@ -61,7 +61,8 @@ _SYMS = {
 HEADER_SYMBOLS = sorted(set(
     [s for t in _SYMS.values() for s in t[:3]] +
     ["read_code_table", "build_symbol_encoder", "free_encoder", "free_huffman_tree",
-     "press_hip_last_error", "press_hip_set_device", "press_hip_set_stream", "press_hip_get_stream",
+     "press_hip_last_error", "press_hip_set_device", "press_hip_set_stream", "press_hip_reset_stream",
+     "press_hip_get_stream",
      "press_hip_synchronize", "press_hip_load_table_file", "press_hip_set_table", "press_hip_bound",
      "press_hip_press_batch", "press_hip_depress_batch", "press_hip_workspace_bytes",
      "press_hip_shutdown"]))

@@ -157,25 +157,33 @@ def _splitmix_t(x):
     return z ^ _lsr(z, 31)
 
 
-def synth_batch_torch(seed, first_read, nreads, device, fixed_len=None, group_samples=1 << 27):
-    """Same reads as synth_batch, generated on `device` -> (int16 tensor, uint64 offsets ndarray)."""
+def synth_batch_torch(seed, first_read, nreads, device, fixed_len=None, group_samples=1 << 27, align=1):
+    """Same reads as synth_batch, generated on `device`.
+
+    -> (int16 tensor, starts uint64 ndarray [nreads+1], n int64 ndarray [nreads]).
+    Read k occupies sig[starts[k] : starts[k] + n[k]]; with align > 1 every start is a
+    multiple of `align` samples (the gaps are zero) and starts[nreads] is the padded
+    total; with align == 1 the layout equals synth_batch's."""
     import torch
 
     n, first = read_lengths(seed, first_read, nreads, fixed_len)
-    off = np.zeros(nreads + 1, dtype=np.uint64)
-    off[1:] = np.cumsum(n)
-    total = int(off[-1])
-    sig = torch.empty(total, dtype=torch.int16, device=device)
+    pad = (n + align - 1) // align * align
+    starts = np.zeros(nreads + 1, dtype=np.uint64)
+    starts[1:] = np.cumsum(pad)
+    total = int(starts[-1])
+    sig = torch.zeros(total, dtype=torch.int16, device=device)
     cdf = torch.from_numpy(cdf32().astype(np.int64)).to(device)
     seedmul = (seed * 0x2545F4914F6CDD1D) & _MASK64
     k0 = 0
     while k0 < nreads:
         k1 = k0 + 1
-        while k1 < nreads and int(off[k1 + 1] - off[k0]) <= group_samples:
+        while k1 < nreads and int(n[k0:k1 + 1].sum()) <= group_samples:
             k1 += 1
         g_n = torch.from_numpy(n[k0:k1]).to(device)
-        g_tot = int(off[k1] - off[k0])
-        g_off = torch.from_numpy((off[k0:k1] - off[k0]).astype(np.int64)).to(device)
+        g_tot = int(n[k0:k1].sum())
+        g_off_np = np.zeros(k1 - k0, dtype=np.int64)
+        g_off_np[1:] = np.cumsum(n[k0:k1])[:-1]
+        g_off = torch.from_numpy(g_off_np).to(device)
         rid = torch.repeat_interleave(torch.arange(k0, k1, device=device, dtype=torch.int64), g_n)
         idx = torch.arange(g_tot, device=device, dtype=torch.int64) - g_off[rid - k0]
         x = (_i64(seedmul) ^ ((rid + first_read) << 32)) + idx * 2
@@ -189,17 +197,23 @@ def synth_batch_torch(seed, first_read, nreads, device, fixed_len=None, group_sa
         del h1, h2, sym, is_ex, low, exv, x
         delta = (z >> 1) ^ -(z & 1)
         del z
-        starts = g_off
-        delta[starts] = torch.from_numpy(first[k0:k1]).to(device)
+        delta[g_off] = torch.from_numpy(first[k0:k1]).to(device)
         w = torch.cumsum(delta, 0)
         # subtract the walk accumulated by the previous reads of this group
         base = torch.zeros(k1 - k0, dtype=torch.int64, device=device)
         if k1 - k0 > 1:
-            base[1:] = w[starts[1:] - 1]
+            base[1:] = w[g_off[1:] - 1]
         w -= base[rid - k0]
-        del delta, rid, idx
+        del delta
         m = torch.remainder(w, FOLD)
-        sig[int(off[k0]): int(off[k1])] = torch.where(m <= 2047, m, FOLD - m).to(torch.int16)
+        vals = torch.where(m <= 2047, m, FOLD - m).to(torch.int16)
         del w, m
+        if align == 1:
+            sig[int(starts[k0]): int(starts[k0]) + g_tot] = vals
+        else:
+            dst = torch.from_numpy(starts[k0:k1].astype(np.int64)).to(device)[rid - k0] + idx
+            sig[dst] = vals
+            del dst
+        del vals, rid, idx
         k0 = k1
-    return sig, off
+    return sig, starts, n

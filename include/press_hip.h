@@ -169,8 +169,11 @@ const char *press_hip_last_error(void);
 
 /* select the device for this process (default: current device).  One process per GPU. */
 int press_hip_set_device(int device);
-/* stream (hipStream_t, as void*) the batch calls enqueue on; NULL = library's own */
+/* stream (hipStream_t, as void*) the batch calls enqueue on; NULL is HIP's default
+ * (null) stream.  Until this is called the library uses a private non-blocking stream;
+ * press_hip_reset_stream() returns to it. */
 int press_hip_set_stream(void *stream);
+int press_hip_reset_stream(void);
 void *press_hip_get_stream(void);
 /* block until everything enqueued by batch calls has finished */
 int press_hip_synchronize(void);

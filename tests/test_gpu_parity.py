@@ -194,18 +194,13 @@ def test_batch_device_resident_roundtrip(oracle):
     dev = torch.device("cuda:0")
     press.use_torch_stream()
     nreads = 64
-    sig, off = synth.synth_batch_torch(3, 0, nreads, dev)
-    n_np = np.diff(off.astype(np.int64))
-    # re-lay out with 8-sample aligned starts
-    pad = (n_np + 7) // 8 * 8
-    starts = np.concatenate([[0], np.cumsum(pad)[:-1]])
-    total = int(pad.sum())
-    sig_al = torch.zeros(total + 64, dtype=torch.int16, device=dev)
-    for k in range(nreads):
-        sig_al[int(starts[k]):int(starts[k]) + int(n_np[k])] = sig[int(off[k]):int(off[k + 1])]
-    d_off = torch.from_numpy(starts.astype(np.int64)).to(dev)
+    sig_al, starts, n_np = synth.synth_batch_torch(3, 0, nreads, dev, align=8)
+    total = int(starts[-1])
+    sig_al = torch.cat([sig_al, torch.zeros(64, dtype=torch.int16, device=dev)])
+    d_off = torch.from_numpy(starts[:-1].astype(np.int64)).to(dev)
     d_n = torch.from_numpy(n_np.astype(np.int32)).to(dev)
-    host = sig.cpu().numpy()
+    off = starts
+    host = sig_al.cpu().numpy()
     for m in ("svb12_zd", "svb_zd", "vbe21_zd", "hasgam_vbsse21_zdq", "shuffman_vbe21_zd"):
         caps = np.array([press.bound(m, int(x)) + 64 for x in n_np], dtype=np.int64)
         caps = (caps + 127) // 128 * 128
@@ -219,7 +214,7 @@ def test_batch_device_resident_roundtrip(oracle):
         assert (lens > 0).all(), m
         want = 0
         for k in (0, 1, nreads - 1):
-            ret, w = oracle.press(m, host[int(off[k]):int(off[k + 1])])
+            ret, w = oracle.press(m, host[int(off[k]):int(off[k]) + int(n_np[k])])
             assert ret == 0
             got = d_out[int(out_off[k]):int(out_off[k]) + int(lens[k])].cpu().numpy().tobytes()
             assert got == w, (m, k)
