@@ -55,11 +55,9 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from honours_amd import press, synth
+    from honours_amd import press, shard, synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = shard.world_info()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
@@ -77,8 +75,8 @@ def main():
     m = args.method
 
     # ---- synthetic batch, generated on the device (never staged through PCIe)
-    R = args.reads
-    sig, starts, n = synth.synth_batch_torch(args.seed, rank * R, R, dev, fixed_len=args.fixed_len, align=64)
+    first_read, R = shard.weak_shard(args.reads, rank)
+    sig, starts, n = synth.synth_batch_torch(args.seed, first_read, R, dev, fixed_len=args.fixed_len, align=64)
     sig = torch.cat([sig, torch.zeros(64, dtype=torch.int16, device=dev)])
     total_samples = int(n.sum())
     raw_bytes = 2 * total_samples
@@ -131,13 +129,8 @@ def main():
     elapsed = t1 - t0
     press_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
     depress_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
-    tot = torch.tensor([raw_bytes, comp_bytes, R], dtype=torch.int64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)  # the only collective: 24 bytes over RCCL
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-    raw_all, comp_all, reads_all = (int(x) for x in tot.tolist())
+    # the only collective: 24 bytes of totals (+ the slowest rank's time) over RCCL
+    raw_all, comp_all, reads_all, elapsed = shard.reduce_totals(raw_bytes, comp_bytes, R, elapsed, dev)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

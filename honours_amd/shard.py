@@ -1,0 +1,43 @@
+"""Multi-GPU sharding of the per-read hot path.
+
+Reads are independent (thesis/probspace/focus.tex:177-183), so the path shards with no
+data exchange: rank k of W owns a contiguous range of the read index; every rank runs
+the same kernels on its own reads, one process per GPU.  The only collective is one
+all-reduce of the {raw bytes, compressed bytes, reads} totals (24 bytes, RCCL over xGMI
+on GPUs, gloo in the CPU tests) plus a MAX-reduce of the elapsed time for reporting.
+"""
+import os
+
+
+def world_info():
+    """(rank, world_size, local_rank) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def shard_range(total_reads, rank, world):
+    """Contiguous, balanced split of [0, total_reads) - rank's [first, first+count)."""
+    base, rem = divmod(total_reads, world)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def weak_shard(reads_per_rank, rank):
+    """Weak scaling (bench.py): every rank owns `reads_per_rank` reads of its own."""
+    return rank * reads_per_rank, reads_per_rank
+
+
+def reduce_totals(raw_bytes, comp_bytes, nreads, elapsed_s, device=None):
+    """Sum the byte/read totals and take the slowest rank's time.  No-op when not
+    running under torch.distributed."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(raw_bytes), int(comp_bytes), int(nreads), float(elapsed_s)
+    tot = torch.tensor([int(raw_bytes), int(comp_bytes), int(nreads)], dtype=torch.int64, device=device)
+    tmax = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    r, c, n = (int(x) for x in tot.tolist())
+    return r, c, n, float(tmax.item())

@@ -1,0 +1,83 @@
+"""CPU, world_size 2 over gloo: the N > 1 path of bench.py - disjoint read shards, the
+totals all-reduce and the max-over-ranks time - with the oracle standing in for the
+kernels (the data path itself has no collective)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total_reads, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _libs
+    from honours_amd import shard, synth
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, count = shard.shard_range(total_reads, rank, world)
+    sig, off = synth.synth_batch(77, first, count, fixed_len=3000)
+    o = _libs.oracle()
+    comp = 0
+    for k in range(count):
+        ret, c = o.press("svb12_zd", sig[int(off[k]):int(off[k + 1])])
+        assert ret == 0
+        comp += len(c)
+    raw, comp_all, nreads, t = shard.reduce_totals(2 * int(off[-1]), comp, count, 1.0 + rank)
+    q.put((rank, first, count, raw, comp_all, nreads, t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_reduce():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _libs
+    from honours_amd import shard, synth
+
+    total_reads, world = 7, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total_reads, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # shards are disjoint and cover the read index
+    assert [(r[1], r[2]) for r in res] == [(0, 4), (4, 3)]
+    # every rank holds the same global totals, equal to a single-process run
+    sig, off = synth.synth_batch(77, 0, total_reads, fixed_len=3000)
+    o = _libs.oracle()
+    comp = sum(len(o.press("svb12_zd", sig[int(off[k]):int(off[k + 1])])[1]) for k in range(total_reads))
+    for r in res:
+        assert r[3:6] == (2 * int(off[-1]), comp, total_reads)
+        assert r[6] == 2.0  # MAX over ranks of (1.0 + rank)
+
+
+def test_shard_range_balanced():
+    from honours_amd import shard
+
+    for total in (0, 1, 7, 8, 500000):
+        for world in (1, 2, 3, 8):
+            parts = [shard.shard_range(total, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == total
+            for a, b in zip(parts, parts[1:]):
+                assert a[0] + a[1] == b[0]
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
