@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpress_hip.so")
-SOURCES = ["press_kernels.hip", "press_abi.hip"]
+SOURCES = ["press_kernels.hip", "press_chunked.hip", "press_abi.hip"]
 HEADERS = ["press_internal.h", os.path.join("..", "..", "include", "press_hip.h")]
 
 
@@ -28,7 +28,7 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB, "-ldl"]
+           "-Wno-unused-function", "-Wno-cast-align"] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB, "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

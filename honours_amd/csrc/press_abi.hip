@@ -80,7 +80,8 @@ struct Ctx {
 	hipStream_t user = nullptr;
 	bool use_user = false;
 	// scratch shared by both modes
-	DevBuf meta, ex_pos, ex_val, low, huff;
+	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl;
+	int use_v1 = -1; // PRESS_HIP_V1=1 selects the one-workgroup-per-read svb kernels (A/B)
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn;
 	// static Huffman table currently on the device
@@ -219,10 +220,30 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 
 int parse_table_file(FILE *fp, uint32_t len[256], uint64_t bits[256]);
 
+uint32_t max_chunks_of(uint64_t total_samples, uint32_t nreads)
+{
+	return (uint32_t) (total_samples / CHUNK + nreads + 1);
+}
+
+bool use_v1()
+{
+	if (g.use_v1 < 0) {
+		const char *e = getenv("PRESS_HIP_V1");
+		g.use_v1 = (e && *e == '1') ? 1 : 0;
+	}
+	return g.use_v1 == 1;
+}
+
 int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool decode)
 {
 	if (g.meta.reserve(((size_t) nreads + 1) * sizeof(ReadMeta)))
 		return PRESS_HIP_EHIP;
+	if (is_svb(method)) {
+		const size_t mc = max_chunks_of(total_samples, nreads);
+		if (g.chunks.reserve(mc * sizeof(ChunkDesc)) || g.gran.reserve(2 * mc * sizeof(uint64_t)) ||
+		    g.ctl.reserve(sizeof(ChunkCtl)))
+			return PRESS_HIP_EHIP;
+	}
 	if (is_ex(method)) {
 		if (g.ex_pos.reserve((total_samples + 64) * 4) || g.ex_val.reserve((total_samples + 64) * 4))
 			return PRESS_HIP_EHIP;
@@ -286,7 +307,7 @@ extern "C" void press_hip_shutdown(void)
 		return;
 	(void) hipSetDevice(g.device);
 	(void) hipStreamSynchronize(g.own);
-	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.sig, &g.off, &g.nsamp,
+	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.chunks, &g.gran, &g.ctl, &g.sig, &g.off, &g.nsamp,
 			  &g.arena, &g.arena_off, &g.lens, &g.lens2, &g.outn };
 	for (DevBuf *b : all)
 		b->release();
@@ -351,10 +372,11 @@ extern "C" uint64_t press_hip_workspace_bytes(int method, uint64_t total_samples
 
 static int launch_press(int method, const BatchArgs &a, hipStream_t s)
 {
+	const bool v1 = use_v1();
 	switch (method) {
-	case PRESS_HIP_SVB12:    launch_svb_encode(a, false, false, s); break;
-	case PRESS_HIP_SVB12_ZD: launch_svb_encode(a, false, true, s); break;
-	case PRESS_HIP_SVB_ZD:   launch_svb_encode(a, true, true, s); break;
+	case PRESS_HIP_SVB12:    v1 ? launch_svb_encode(a, false, false, s) : launch_svb_encode_chunked(a, false, false, s); break;
+	case PRESS_HIP_SVB12_ZD: v1 ? launch_svb_encode(a, false, true, s) : launch_svb_encode_chunked(a, false, true, s); break;
+	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_encode(a, true, true, s) : launch_svb_encode_chunked(a, true, true, s); break;
 	default:
 		launch_ex_encode(a, exfmt_of(method), is_shuff(method), s);
 	}
@@ -366,10 +388,11 @@ static int launch_press(int method, const BatchArgs &a, hipStream_t s)
 
 static int launch_depress(int method, const DecodeArgs &a, hipStream_t s)
 {
+	const bool v1 = use_v1();
 	switch (method) {
-	case PRESS_HIP_SVB12:    launch_svb_decode(a, false, false, s); break;
-	case PRESS_HIP_SVB12_ZD: launch_svb_decode(a, false, true, s); break;
-	case PRESS_HIP_SVB_ZD:   launch_svb_decode(a, true, true, s); break;
+	case PRESS_HIP_SVB12:    v1 ? launch_svb_decode(a, false, false, s) : launch_svb_decode_chunked(a, false, false, s); break;
+	case PRESS_HIP_SVB12_ZD: v1 ? launch_svb_decode(a, false, true, s) : launch_svb_decode_chunked(a, false, true, s); break;
+	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_decode(a, true, true, s) : launch_svb_decode_chunked(a, true, true, s); break;
 	default:
 		launch_ex_decode(a, exfmt_of(method), is_shuff(method), s);
 	}
@@ -412,6 +435,10 @@ extern "C" int press_hip_press_batch(int method, const int16_t *sig, const uint6
 	a.ex_pos = (uint32_t *) g.ex_pos.p;
 	a.ex_val = (uint32_t *) g.ex_val.p;
 	a.huff = (const HuffDev *) g.huff.p;
+	a.chunks = (ChunkDesc *) g.chunks.p;
+	a.gran = (uint64_t *) g.gran.p;
+	a.ctl = (ChunkCtl *) g.ctl.p;
+	a.max_chunks = max_chunks_of(total_samples, nreads);
 
 	if (device_resident) {
 		if ((uintptr_t) sig & 15)
@@ -495,6 +522,10 @@ extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint
 	a.ex_val = (uint32_t *) g.ex_val.p;
 	a.low = (uint8_t *) g.low.p;
 	a.huff = (const HuffDev *) g.huff.p;
+	a.chunks = (ChunkDesc *) g.chunks.p;
+	a.gran = (uint64_t *) g.gran.p;
+	a.ctl = (ChunkCtl *) g.ctl.p;
+	a.max_chunks = max_chunks_of(total_samples, nreads);
 
 	if (device_resident) {
 		if ((uintptr_t) sig & 15)

@@ -1,0 +1,416 @@
+// press_chunked.hip - v2 svb16 / svb32 kernels for gfx950: chunked, register resident,
+// wave autonomous.
+//
+// A read is cut into chunks of CHUNK = 32768 samples; one 256-thread workgroup per chunk,
+// handed out in ticket order.  Each of the 4 waves owns a contiguous quarter of the chunk
+// (8192 samples = 16 sub-tiles of 512 samples; a lane holds 8 samples = one dwordx4 per
+// sub-tile), so
+//   * all 16 loads of a lane are issued back to back (64 KiB in flight per workgroup) and
+//     the zig-zag-delta values stay in registers as packed 16-bit pairs
+//     (v_alignbit + v_pk_sub_i16 + v_pk_lshlrev/ashrrev + v_xor per pair);
+//   * a sub-tile without exceptions (98 % of them on NA12878-like data) is written with
+//     two v_perm_b32 and ONE 8-byte global store per lane at an unaligned address
+//     (unaligned dwordx2 stores run at 0.9x the aligned rate on MI355X,
+//     tools/ubench_unaligned.hip); a sub-tile with exceptions takes a wave scan and the
+//     few lanes that hold an exception store byte-wise.  No LDS staging, no barrier in
+//     the data path;
+//   * what chains the chunks of a read is only the NUMBER of exceptions before the chunk
+//     (the byte offset of sample i is i + #exceptions before i): a decoupled look-back
+//     over 8-byte {status,count} granules, each written by one relaxed agent-scope atomic
+//     store (cdna_hip_programming.md Guideline 16, form R2: the data is the flag).
+//     Ticket order makes the look-back deadlock free: every predecessor of a chunk was
+//     taken by a workgroup that is already running.
+//
+// Formats: svb16/encode.hpp:11, encode_scalar.hpp:14, decode.hpp:23, decode_scalar.hpp:31;
+// streamvbyte_encode.c:70, streamvbyte_decode.c:62; press.c:1573-1611, 1678-1694.
+
+#include "press_internal.h"
+
+namespace ph {
+
+constexpr int CWG = 256;                     // threads per workgroup
+constexpr int CK = 16;                       // sub-tiles per wave
+constexpr uint32_t SUB = 512;                // samples per sub-tile (64 lanes x 8)
+constexpr uint32_t WAVE_SAMPLES = CK * SUB;  // 8192
+static_assert(WAVE_SAMPLES * 4 == CHUNK, "chunk = 4 waves");
+
+constexpr uint64_t G_A = 1ull << 62;         // granule: aggregate of this chunk only
+constexpr uint64_t G_P = 2ull << 62;         // granule: inclusive prefix up to this chunk
+constexpr uint64_t G_MASK = (1ull << 62) - 1;
+constexpr uint64_t CFAIL64 = ~0ull;
+constexpr uint32_t CFAIL32 = 0xFFFFFFFFu;
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef uint2 __attribute__((aligned(1))) uint2_u; // 8-byte access at any byte address
+typedef uint16_t __attribute__((aligned(1))) u16_u;
+
+__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v)
+{
+	const int lane = threadIdx.x & 63;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t t = __shfl_up(v, d, 64);
+		if (lane >= d)
+			v += t;
+	}
+	return v;
+}
+
+// value of the previous lane (lane 0 receives `lane0`)
+__device__ __forceinline__ uint32_t prev_lane(uint32_t v, uint32_t lane0)
+{
+	// DPP wave_shr:1 - lane l reads lane l-1; lane 0 keeps `old`
+	return (uint32_t) __builtin_amdgcn_update_dpp((int) lane0, (int) v, 0x138, 0xf, 0xf, false);
+}
+
+// zig-zag delta of the two samples packed in `cur`, given the dword holding the two
+// samples before them (trans.c:75,215 on packed 16-bit lanes)
+__device__ __forceinline__ uint32_t zd_pair(uint32_t cur, uint32_t prevdw)
+{
+	const uint32_t sh = __builtin_amdgcn_alignbit(cur, prevdw, 16); // [prev.hi, cur.lo]
+	const s16x2 d = __builtin_bit_cast(s16x2, cur) - __builtin_bit_cast(s16x2, sh);
+	const s16x2 z = (d << 1) ^ (d >> 15);
+	return __builtin_bit_cast(uint32_t, z);
+}
+
+// relaxed agent-scope granule access (sc1: L2-coherent, bypasses this CU's L1)
+__device__ __forceinline__ void gran_store(uint64_t *g, uint64_t v)
+{
+	__hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t gran_load(uint64_t *g)
+{
+	return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Decoupled look-back (one lane): publish this chunk's aggregate, sum the aggregates of the
+// chunks before it in the same read, publish the inclusive prefix.  `t` = this chunk's
+// ticket, j = its index in the read (chunk t-j is the read's first).  Returns the exclusive
+// prefix.  `last`: no chunk of this read follows, nothing needs publishing.
+__device__ __forceinline__ uint64_t lookback(uint64_t *gran, uint32_t t, uint32_t j, uint64_t mine, bool last)
+{
+	if (j == 0) {
+		if (!last)
+			gran_store(gran + t, G_P | mine);
+		return 0;
+	}
+	if (!last)
+		gran_store(gran + t, G_A | mine);
+	uint64_t sum = 0;
+	for (uint32_t i = t - 1;; i--) {
+		uint64_t g = gran_load(gran + i);
+		while ((g >> 62) == 0) {
+			__builtin_amdgcn_s_sleep(2);
+			g = gran_load(gran + i);
+		}
+		sum += g & G_MASK;
+		if ((g >> 62) == 2)
+			break;
+	}
+	if (!last)
+		gran_store(gran + t, G_P | (sum + mine));
+	return sum;
+}
+
+// ------------------------------------------------------------------ chunk table
+
+// One block: chunk counts per read -> exclusive scan -> one descriptor per chunk.
+template <bool DEC, bool KEY2>
+__global__ __launch_bounds__(1024) void k_chunk_prep(const uint64_t *off, const uint32_t *nsamp,
+						     const uint64_t *slot_off, const uint64_t *in_len,
+						     uint32_t nreads, ChunkDesc *chunks, ChunkCtl *ctl,
+						     uint32_t max_chunks, uint64_t *out_len, uint32_t *out_n)
+{
+	__shared__ uint32_t wtot[16];
+	__shared__ uint32_t carry_s;
+	if (threadIdx.x == 0)
+		carry_s = 0;
+	__syncthreads();
+	for (uint32_t r0 = 0; r0 < nreads; r0 += 1024) {
+		const uint32_t r = r0 + threadIdx.x;
+		uint32_t n = 0, nch = 0;
+		if (r < nreads) {
+			n = nsamp[r];
+			nch = (n + CHUNK - 1) / CHUNK;
+		}
+		const uint32_t inc = wave_incl_scan32(nch);
+		if ((threadIdx.x & 63) == 63)
+			wtot[threadIdx.x >> 6] = inc;
+		__syncthreads();
+		uint32_t base = carry_s;
+		for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
+			base += wtot[w];
+		const uint32_t first = base + inc - nch;
+		if (r < nreads) {
+			const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
+			uint32_t ok;
+			uint64_t sbase;
+			if (!DEC) {
+				sbase = slot_off[r];
+				ok = (uint64_t) klen + 2ull * n <= slot_off[r + 1] - sbase;
+			} else {
+				sbase = slot_off[r];
+				ok = klen <= in_len[r];
+			}
+			if (n == 0) {
+				if (!DEC)
+					out_len[r] = 0;
+				else
+					out_n[r] = 0;
+			}
+			for (uint32_t j = 0; j < nch; j++) {
+				if (first + j >= max_chunks)
+					break; // cannot happen: max_chunks bounds the sum
+				ChunkDesc d;
+				d.sig_off = off[r];
+				d.out_base = sbase;
+				d.n = n;
+				d.j = j;
+				d.read = r;
+				d.cap_ok = ok;
+				chunks[first + j] = d;
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x == 1023)
+			carry_s = base + inc;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+		ctl->nchunks = carry_s < max_chunks ? carry_s : max_chunks;
+}
+
+// ------------------------------------------------------------------ encode
+
+template <bool KEY2, bool ZD>
+__global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
+{
+	__shared__ uint32_t s_ticket;
+	__shared__ uint32_t s_wtot[4];
+	__shared__ uint64_t s_excl;
+
+	// persistent workgroups: chunks are handed out in ticket order (what makes the
+	// look-back deadlock free).  (Fetching the next ticket early was measured slower.)
+	const uint32_t nchunks = a.ctl->nchunks;
+	for (;;) {
+	if (threadIdx.x == 0)
+		s_ticket = atomicAdd(&a.ctl->ticket, 1u);
+	__syncthreads();
+	const uint32_t t = s_ticket;
+	if (t >= nchunks)
+		break;
+	const ChunkDesc d = a.chunks[t];
+	const uint32_t n = d.n;
+	const uint32_t first = d.j * CHUNK;          // first sample of the chunk within the read
+	const bool last = first + CHUNK >= n;
+	const int lane = threadIdx.x & 63;
+	const int w = threadIdx.x >> 6;
+
+	if (!d.cap_ok) { // slot smaller than the worst case of the format: fail the read
+		if (threadIdx.x == 0) {
+			(void) lookback(a.gran, t, d.j, 0, last);
+			if (last)
+				a.out_len[d.read] = CFAIL64;
+		}
+		__syncthreads(); // every wave has read s_ticket before thread 0 overwrites it
+		continue;
+	}
+
+	const int16_t *in = a.sig + d.sig_off;
+	uint8_t *out = a.out + d.out_base;
+	const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
+	const uint32_t ws = first + w * WAVE_SAMPLES; // first sample of this wave's quarter
+
+	// ---- phase 1: load everything, zig-zag delta in registers, count exceptions
+	uint4 z[CK];
+#pragma unroll
+	for (int k = 0; k < CK; k++) {
+		const uint32_t i0 = ws + k * SUB + lane * 8;
+		z[k] = make_uint4(0, 0, 0, 0);
+		if (i0 < n)
+			z[k] = *reinterpret_cast<const uint4 *>(in + i0);
+	}
+	uint32_t carry = 0; // dword holding the sample in front of lane 0's first sample
+	if (ZD && ws > 0 && ws < n)
+		carry = (uint32_t) (uint16_t) in[ws - 1] << 16;
+
+	uint32_t kmask = 0;  // sub-tiles that need the slow path (exceptions or a ragged tail)
+	uint32_t etot = 0;   // exceptions in this wave's quarter (uniform)
+#pragma unroll
+	for (int k = 0; k < CK; k++) {
+		const uint32_t i0 = ws + k * SUB + lane * 8;
+		const uint32_t raw_w = z[k].w;
+		if (ZD) {
+			const uint32_t pw = prev_lane(raw_w, carry);
+			const uint32_t z0 = zd_pair(z[k].x, pw);
+			const uint32_t z1 = zd_pair(z[k].y, z[k].x);
+			const uint32_t z2 = zd_pair(z[k].z, z[k].y);
+			const uint32_t z3 = zd_pair(z[k].w, z[k].z);
+			z[k] = make_uint4(z0, z1, z2, z3);
+			carry = (uint32_t) __builtin_amdgcn_readlane((int) raw_w, 63);
+		}
+		// samples at or beyond n must not count: zero them
+		if (i0 + 8 > n) {
+			const uint32_t nv = i0 < n ? n - i0 : 0;
+			uint32_t zz[4] = { z[k].x, z[k].y, z[k].z, z[k].w };
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				if (nv <= (uint32_t) (2 * q))
+					zz[q] = 0;
+				else if (nv == (uint32_t) (2 * q + 1))
+					zz[q] &= 0xFFFFu;
+			}
+			z[k] = make_uint4(zz[0], zz[1], zz[2], zz[3]);
+		}
+		const uint32_t hi = (z[k].x | z[k].y | z[k].z | z[k].w) & 0xFF00FF00u;
+		const bool ragged = i0 < n && i0 + 8 > n;
+		const unsigned long long bx = __ballot(hi != 0);
+		const unsigned long long br = __ballot(ragged);
+		if (bx | br)
+			kmask |= 1u << k;
+		if (bx) {
+			// exact count: one popcount of a ballot per key bit
+			const uint32_t zz[4] = { z[k].x, z[k].y, z[k].z, z[k].w };
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				etot += (uint32_t) __popcll(__ballot((zz[q] & 0x0000FF00u) != 0));
+				etot += (uint32_t) __popcll(__ballot((zz[q] & 0xFF000000u) != 0));
+			}
+		}
+	}
+
+	// ---- exceptions before this wave: within the chunk (LDS) and before the chunk (look-back)
+	if (lane == 0)
+		s_wtot[w] = etot;
+	__syncthreads();
+	const uint32_t t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
+#ifdef EXP_NO_LOOKBACK
+	if (threadIdx.x == 0)
+		s_excl = 0;
+#else
+	if (threadIdx.x == 0)
+		s_excl = lookback(a.gran, t, d.j, (uint64_t) t0 + t1 + t2 + t3, last);
+#endif
+	__syncthreads();
+	const uint64_t ebefore = s_excl;
+	uint64_t ebase = ebefore + (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
+	if (last && threadIdx.x == 0)
+		a.out_len[d.read] = (uint64_t) klen + n + ebefore + t0 + t1 + t2 + t3;
+
+	// ---- phase 2: keys and data
+	uint8_t *data = out + klen;
+#pragma unroll
+	for (int k = 0; k < CK; k++) {
+		const uint32_t i0 = ws + k * SUB + lane * 8;
+		if (ws + k * SUB >= n)
+			break; // uniform: nothing left in this wave's quarter
+		const uint32_t zz[4] = { z[k].x, z[k].y, z[k].z, z[k].w };
+		const uint32_t lo0 = __builtin_amdgcn_perm(zz[1], zz[0], 0x06040200);
+		const uint32_t lo1 = __builtin_amdgcn_perm(zz[3], zz[2], 0x06040200);
+		if (!((kmask >> k) & 1u)) {
+			// fast path: no exception, no ragged tail in the whole sub-tile (lanes are
+			// either complete or entirely beyond the end of the read)
+			if (i0 < n) {
+#ifndef EXP_NO_KEYS
+				if (!KEY2)
+					out[i0 >> 3] = 0;
+				else
+					*reinterpret_cast<u16_u *>(out + (i0 >> 2)) = 0;
+#endif
+				uint2 v;
+				v.x = lo0;
+				v.y = lo1;
+#ifndef EXP_NO_DATA
+				*reinterpret_cast<uint2_u *>(data + ebase + i0) = v;
+#else
+				if (lo0 == 0x12345678 && lo1 == 0x9abcdef0) *reinterpret_cast<uint2_u *>(data + ebase + i0) = v;
+#endif
+			}
+			continue;
+		}
+		// slow path
+		uint32_t key = 0;
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			key |= ((zz[q] & 0x0000FF00u) ? 1u : 0u) << (2 * q);
+			key |= ((zz[q] & 0xFF000000u) ? 1u : 0u) << (2 * q + 1);
+		}
+		const uint32_t nv = i0 < n ? min(8u, n - i0) : 0u;
+		const uint32_t cnt = __popc(key);
+		const uint32_t inc = wave_incl_scan32(cnt);
+		const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+		uint8_t *p = data + ebase + i0 + (inc - cnt);
+		if (nv) {
+			if (!KEY2) {
+				out[i0 >> 3] = (uint8_t) key;
+			} else {
+				uint32_t k0 = 0, k1 = 0;
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					k0 |= ((key >> q) & 1u) << (2 * q);
+					k1 |= ((key >> (q + 4)) & 1u) << (2 * q);
+				}
+				out[i0 >> 2] = (uint8_t) k0;
+				if (nv > 4)
+					out[(i0 >> 2) + 1] = (uint8_t) k1;
+			}
+			if (nv == 8 && cnt == 0) {
+				uint2 v;
+				v.x = lo0;
+				v.y = lo1;
+				*reinterpret_cast<uint2_u *>(p) = v;
+			} else {
+#pragma unroll
+				for (int q = 0; q < 8; q++) {
+					if ((uint32_t) q < nv) {
+						const uint32_t val = (zz[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+						*p++ = (uint8_t) val;
+						if (val > 255u)
+							*p++ = (uint8_t) (val >> 8);
+					}
+				}
+			}
+		}
+		ebase += tot;
+	}
+	} // ticket loop
+}
+
+// ------------------------------------------------------------------ launchers
+
+template <bool KEY2, bool ZD>
+static void run_encode(const BatchArgs &a, hipStream_t s)
+{
+	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
+	(void) hipMemsetAsync(a.gran, 0, (size_t) a.max_chunks * sizeof(uint64_t), s);
+	hipLaunchKernelGGL((k_chunk_prep<false, KEY2>), dim3(1), dim3(1024), 0, s, a.off, a.nsamp, a.out_off,
+			   (const uint64_t *) nullptr, a.nreads, a.chunks, a.ctl, a.max_chunks, a.out_len,
+			   (uint32_t *) nullptr);
+	// persistent grid: enough workgroups to fill the chip twice over (4 resident per CU)
+#ifndef EXP_GRID
+#define EXP_GRID 2048u
+#endif
+	const uint32_t grid = a.max_chunks < EXP_GRID ? a.max_chunks : EXP_GRID;
+	hipLaunchKernelGGL((k_svb_encode_chunked<KEY2, ZD>), dim3(grid), dim3(CWG), 0, s, a);
+}
+
+void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s)
+{
+	if (!a.nreads || !a.max_chunks)
+		return;
+	if (key2bit)
+		run_encode<true, true>(a, s);
+	else if (zd)
+		run_encode<false, true>(a, s);
+	else
+		run_encode<false, false>(a, s);
+}
+
+void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s)
+{
+	// v2 decode lands next; the v1 kernel is the decode path for now
+	launch_svb_decode(a, key2bit, zd, s);
+}
+
+} // namespace ph

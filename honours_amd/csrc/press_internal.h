@@ -37,6 +37,26 @@ struct HuffDev {
 	int16_t leaf[1024];                // symbol at a leaf, -1 otherwise
 };
 
+// ---- chunked (v2) svb kernels: a read is cut into chunks of CHUNK samples, one workgroup
+// per chunk; chunks of a read are chained by a decoupled look-back over 8-byte granules.
+constexpr uint32_t CHUNK = 32768;           // samples per chunk: 4 waves x 16 sub-tiles x 512
+struct ChunkDesc {                          // written by k_chunk_prep, one per chunk (32 bytes)
+	uint64_t sig_off;   // sample offset of the READ in sig
+	uint64_t out_base;  // byte offset of the read's slot in the arena
+	uint32_t n;         // samples in the read
+	uint32_t j;         // chunk index within the read
+	uint32_t read;      // read index
+	uint32_t cap_ok;    // slot large enough for the worst case of the format
+};
+struct ChunkCtl {                           // device control block; every word on its own 128-B line
+	uint32_t ticket;    // next chunk to hand out (atomic)
+	uint32_t pad0[31];
+	uint32_t nchunks;   // written by k_chunk_prep, read by every workgroup
+	uint32_t pad1[31];
+	uint32_t ticket2;   // second ticket (decode)
+	uint32_t pad2[31];
+};
+
 // Arguments common to every batch kernel.
 struct BatchArgs {
 	const int16_t *sig;       // samples of all reads
@@ -50,6 +70,11 @@ struct BatchArgs {
 	uint32_t *ex_val;         // [total samples] raw exception values
 	const HuffDev *huff;
 	uint32_t nreads;
+	// chunked kernels
+	ChunkDesc *chunks;        // [max_chunks]
+	uint64_t *gran;           // [max_chunks] look-back granules (zeroed per launch)
+	ChunkCtl *ctl;            // zeroed per launch
+	uint32_t max_chunks;      // >= sum over reads of ceil(n / CHUNK)
 };
 
 struct DecodeArgs {
@@ -66,10 +91,17 @@ struct DecodeArgs {
 	uint8_t *low;             // [total samples] Huffman-decoded one-byte stream of read r at low[off[r]..]
 	const HuffDev *huff;
 	uint32_t nreads;
+	// chunked kernels
+	ChunkDesc *chunks;
+	uint64_t *gran;           // [2 * max_chunks]: byte-offset chain, then sample-value chain
+	ChunkCtl *ctl;
+	uint32_t max_chunks;
 };
 
 // launchers (press_kernels.hip).  All asynchronous on `s`.
-void launch_svb_encode(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s);
+void launch_svb_encode(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s);      // v1: one workgroup per read
+void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s); // v2: chunks + look-back
+void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s);
 void launch_svb_decode(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s);
 // exception-split encode: scan (+ qts redo for ex-zd) -> section -> one-byte / Huffman stream
 void launch_ex_encode(const BatchArgs &a, int fmt, bool huff, hipStream_t s);

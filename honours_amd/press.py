@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpress_hip.so")
+LIB_PATH = os.environ.get("PRESS_HIP_LIB", os.path.join(_HERE, "libpress_hip.so"))  # override: diagnostic builds
 TABLE_PATH = os.path.join(_HERE, "data", "NA12878_zd.huffman")
 
 # include/press_hip.h enum press_hip_method
