@@ -42,8 +42,6 @@ constexpr uint32_t CFAIL32 = 0xFFFFFFFFu;
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-typedef uint2 __attribute__((aligned(1))) uint2_u; // 8-byte access at any byte address
-typedef uint16_t __attribute__((aligned(1))) u16_u;
 
 __device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v)
 {
@@ -115,70 +113,59 @@ __device__ __forceinline__ uint64_t lookback(uint64_t *gran, uint32_t t, uint32_
 
 // ------------------------------------------------------------------ chunk table
 
-// One block: chunk counts per read -> exclusive scan -> one descriptor per chunk.
+// One thread per read: a wave adds up its reads' chunk counts, takes a contiguous range of
+// chunk ids with ONE atomic (ids need only be contiguous and ascending within a read),
+// writes the descriptors and clears the look-back granules of its chunks.
 template <bool DEC, bool KEY2>
-__global__ __launch_bounds__(1024) void k_chunk_prep(const uint64_t *off, const uint32_t *nsamp,
-						     const uint64_t *slot_off, const uint64_t *in_len,
-						     uint32_t nreads, ChunkDesc *chunks, ChunkCtl *ctl,
-						     uint32_t max_chunks, uint64_t *out_len, uint32_t *out_n)
+__global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const uint32_t *nsamp,
+						    const uint64_t *slot_off, const uint64_t *in_len,
+						    uint32_t nreads, ChunkDesc *chunks, uint64_t *gran,
+						    ChunkCtl *ctl, uint32_t max_chunks, uint64_t *out_len,
+						    uint32_t *out_n)
 {
-	__shared__ uint32_t wtot[16];
-	__shared__ uint32_t carry_s;
-	if (threadIdx.x == 0)
-		carry_s = 0;
-	__syncthreads();
-	for (uint32_t r0 = 0; r0 < nreads; r0 += 1024) {
-		const uint32_t r = r0 + threadIdx.x;
-		uint32_t n = 0, nch = 0;
-		if (r < nreads) {
-			n = nsamp[r];
-			nch = (n + CHUNK - 1) / CHUNK;
-		}
-		const uint32_t inc = wave_incl_scan32(nch);
-		if ((threadIdx.x & 63) == 63)
-			wtot[threadIdx.x >> 6] = inc;
-		__syncthreads();
-		uint32_t base = carry_s;
-		for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
-			base += wtot[w];
-		const uint32_t first = base + inc - nch;
-		if (r < nreads) {
-			const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
-			uint32_t ok;
-			uint64_t sbase;
-			if (!DEC) {
-				sbase = slot_off[r];
-				ok = (uint64_t) klen + 2ull * n <= slot_off[r + 1] - sbase;
-			} else {
-				sbase = slot_off[r];
-				ok = klen <= in_len[r];
-			}
-			if (n == 0) {
-				if (!DEC)
-					out_len[r] = 0;
-				else
-					out_n[r] = 0;
-			}
-			for (uint32_t j = 0; j < nch; j++) {
-				if (first + j >= max_chunks)
-					break; // cannot happen: max_chunks bounds the sum
-				ChunkDesc d;
-				d.sig_off = off[r];
-				d.out_base = sbase;
-				d.n = n;
-				d.j = j;
-				d.read = r;
-				d.cap_ok = ok;
-				chunks[first + j] = d;
-			}
-		}
-		__syncthreads();
-		if (threadIdx.x == 1023)
-			carry_s = base + inc;
-		__syncthreads();
+	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	uint32_t n = 0, nch = 0;
+	if (r < nreads) {
+		n = nsamp[r];
+		nch = (n + CHUNK - 1) / CHUNK;
 	}
-	if (threadIdx.x == 0)
-		ctl->nchunks = carry_s < max_chunks ? carry_s : max_chunks;
+	const uint32_t inc = wave_incl_scan32(nch);
+	uint32_t base = 0;
+	if ((threadIdx.x & 63) == 63 && inc)
+		base = atomicAdd(&ctl->nchunks, inc);
+	base = (uint32_t) __builtin_amdgcn_readlane((int) base, 63);
+	const uint32_t first = base + inc - nch;
+	if (r >= nreads)
+		return;
+	const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
+	const uint64_t sbase = slot_off[r];
+	uint32_t ok;
+	if (!DEC)
+		ok = (uint64_t) klen + 2ull * n <= slot_off[r + 1] - sbase;
+	else
+		ok = klen <= in_len[r];
+	if (n == 0) {
+		if (!DEC)
+			out_len[r] = 0;
+		else
+			out_n[r] = 0;
+	}
+	const uint64_t o = off[r];
+	for (uint32_t j = 0; j < nch; j++) {
+		if (first + j >= max_chunks)
+			break; // cannot happen: max_chunks bounds the sum
+		ChunkDesc d;
+		d.sig_off = o;
+		d.out_base = sbase;
+		d.n = n;
+		d.j = j;
+		d.read = r;
+		d.cap_ok = ok;
+		chunks[first + j] = d;
+		gran[first + j] = 0;
+		if (DEC)
+			gran[max_chunks + first + j] = 0;
+	}
 }
 
 // ------------------------------------------------------------------ encode
@@ -304,7 +291,7 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 	for (int k = 0; k < CK; k++) {
 		const uint32_t i0 = ws + k * SUB + lane * 8;
 		if (ws + k * SUB >= n)
-			break; // uniform: nothing left in this wave's quarter
+			continue; // uniform: nothing left in this wave's quarter
 		const uint32_t zz[4] = { z[k].x, z[k].y, z[k].z, z[k].w };
 		const uint32_t lo0 = __builtin_amdgcn_perm(zz[1], zz[0], 0x06040200);
 		const uint32_t lo1 = __builtin_amdgcn_perm(zz[3], zz[2], 0x06040200);
@@ -316,15 +303,15 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 				if (!KEY2)
 					out[i0 >> 3] = 0;
 				else
-					*reinterpret_cast<u16_u *>(out + (i0 >> 2)) = 0;
+					__builtin_memset(out + (i0 >> 2), 0, 2);
 #endif
 				uint2 v;
 				v.x = lo0;
 				v.y = lo1;
 #ifndef EXP_NO_DATA
-				*reinterpret_cast<uint2_u *>(data + ebase + i0) = v;
+				__builtin_memcpy(data + ebase + i0, &v, 8);
 #else
-				if (lo0 == 0x12345678 && lo1 == 0x9abcdef0) *reinterpret_cast<uint2_u *>(data + ebase + i0) = v;
+				if (lo0 == 0x12345678 && lo1 == 0x9abcdef0) __builtin_memcpy(data + ebase + i0, &v, 8);
 #endif
 			}
 			continue;
@@ -359,7 +346,7 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 				uint2 v;
 				v.x = lo0;
 				v.y = lo1;
-				*reinterpret_cast<uint2_u *>(p) = v;
+				__builtin_memcpy(p, &v, 8);
 			} else {
 #pragma unroll
 				for (int q = 0; q < 8; q++) {
@@ -383,10 +370,9 @@ template <bool KEY2, bool ZD>
 static void run_encode(const BatchArgs &a, hipStream_t s)
 {
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
-	(void) hipMemsetAsync(a.gran, 0, (size_t) a.max_chunks * sizeof(uint64_t), s);
-	hipLaunchKernelGGL((k_chunk_prep<false, KEY2>), dim3(1), dim3(1024), 0, s, a.off, a.nsamp, a.out_off,
-			   (const uint64_t *) nullptr, a.nreads, a.chunks, a.ctl, a.max_chunks, a.out_len,
-			   (uint32_t *) nullptr);
+	hipLaunchKernelGGL((k_chunk_prep<false, KEY2>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
+			   a.nsamp, a.out_off, (const uint64_t *) nullptr, a.nreads, a.chunks, a.gran, a.ctl,
+			   a.max_chunks, a.out_len, (uint32_t *) nullptr);
 	// persistent grid: enough workgroups to fill the chip twice over (4 resident per CU)
 #ifndef EXP_GRID
 #define EXP_GRID 2048u
