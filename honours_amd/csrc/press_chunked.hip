@@ -364,6 +364,337 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 	} // ticket loop
 }
 
+// ------------------------------------------------------------------ decode
+//
+// Chunk j of a read needs two things from the chunks before it: the number of exceptions
+// (its data bytes start at klen + j*CHUNK + E) and the value of the last sample (the
+// deltas are a running sum, trans.c:260).  E comes from the key bytes alone, so it is
+// published before any data is touched; the sample value is published after the chunk
+// has summed its own deltas.  Two look-back chains over the same ticket order.
+//
+// The payload a lane keeps between the phases is the COMPRESSED form (8 bytes per 8
+// samples, 32 VGPRs per chunk quarter) plus one 16-bit base per sub-tile; values are
+// expanded twice (once to sum the deltas, once to store) - ALU is cheap, registers are
+// what bounds the number of chunks in flight per CU.
+
+// inclusive wave scan with DPP (row_shr 1,2,4,8 inside rows of 16, then row_bcast 15 / 31)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v)
+{
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, true); // row_shr:1
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, true); // row_shr:2
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, true); // row_shr:4
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, true); // row_shr:8
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
+	return v;
+}
+
+// inverse zig-zag of two packed 16-bit values (trans.c:80)
+__device__ __forceinline__ uint32_t unzz_pair(uint32_t z)
+{
+	const u16x2 v = __builtin_bit_cast(u16x2, z);
+	const u16x2 one = { 1, 1 };
+	const u16x2 zero = { 0, 0 };
+	const u16x2 r = (v >> one) ^ (zero - (v & one));
+	return __builtin_bit_cast(uint32_t, r);
+}
+
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b)
+{
+	return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
+}
+
+// running sums of the 8 packed deltas of a lane: d[q] = [s(2q), s(2q+1)]; returns the total
+__device__ __forceinline__ uint32_t lane_prefix8(uint32_t d[4])
+{
+	uint32_t run = 0; // previous total in both halves
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		uint32_t t = d[q] + (d[q] << 16);             // [a, a+b]
+		t = pk_add16(t, run);
+		d[q] = t;
+		run = __builtin_amdgcn_perm(t, t, 0x03020302); // broadcast the high half
+	}
+	return run >> 16;
+}
+
+// key bits (svb16) / 2-bit codes (svb32) of the 8 samples at i0, masked to the valid ones
+template <bool KEY2>
+__device__ __forceinline__ uint32_t load_key(const uint8_t *in, uint32_t i0, uint32_t n)
+{
+	uint32_t kk = 0;
+	if (i0 < n) {
+		if (!KEY2) {
+			kk = in[i0 >> 3];
+		} else {
+			kk = in[i0 >> 2];
+			if (i0 + 4 < n)
+				kk |= (uint32_t) in[(i0 >> 2) + 1] << 8;
+		}
+		const uint32_t nv = n - i0;
+		if (nv < 8)
+			kk &= KEY2 ? ((1u << (2 * nv)) - 1u) : ((1u << nv) - 1u);
+	}
+	return kk;
+}
+
+template <bool KEY2>
+__device__ __forceinline__ uint32_t key_extra_bytes(uint32_t kk)
+{
+	if (!KEY2)
+		return __popc(kk);
+	uint32_t c = 0;
+#pragma unroll
+	for (int q = 0; q < 8; q++)
+		c += (kk >> (2 * q)) & 3u;
+	return c;
+}
+
+// Slow path of one sub-tile (exceptions, a ragged tail, or the end of the stream is near):
+// byte-wise, bounds-checked gather of the lane's values into packed 16-bit pairs.
+// `eb` = exceptions in front of the sub-tile; returns the sub-tile's exception count.
+template <bool KEY2>
+__device__ __forceinline__ uint32_t gather_slow(const uint8_t *in, const uint8_t *data, uint64_t dlen,
+						uint32_t i0, uint32_t n, uint64_t eb, uint32_t v[4])
+{
+	const uint32_t kk = load_key<KEY2>(in, i0, n);
+	const uint32_t c = key_extra_bytes<KEY2>(kk);
+	const uint32_t inc = wave_incl_scan_dpp(c);
+	const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+	uint64_t p = eb + i0 + (inc - c);
+	const uint32_t nv = i0 < n ? min(8u, n - i0) : 0u;
+	v[0] = v[1] = v[2] = v[3] = 0;
+#pragma unroll
+	for (int q = 0; q < 8; q++) {
+		if ((uint32_t) q < nv) {
+			const uint32_t code = KEY2 ? ((kk >> (2 * q)) & 3u) : ((kk >> q) & 1u);
+			uint32_t val = p < dlen ? data[p] : 0u;
+			if (code >= 1)
+				val |= (p + 1 < dlen ? (uint32_t) data[p + 1] : 0u) << 8;
+			p += 1 + code;
+			v[q >> 1] |= val << (16 * (q & 1));
+		}
+	}
+	return tot;
+}
+
+// 8 one-byte values -> 4 packed pairs
+__device__ __forceinline__ void expand8(uint2 dd, uint32_t v[4])
+{
+	v[0] = __builtin_amdgcn_perm(0, dd.x, 0x0c010c00);
+	v[1] = __builtin_amdgcn_perm(0, dd.x, 0x0c030c02);
+	v[2] = __builtin_amdgcn_perm(0, dd.y, 0x0c010c00);
+	v[3] = __builtin_amdgcn_perm(0, dd.y, 0x0c030c02);
+}
+
+template <bool KEY2, bool ZD>
+__global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
+{
+	__shared__ uint32_t s_ticket;
+	__shared__ uint64_t s_wtot[4];
+	__shared__ uint32_t s_wsum[4];
+	__shared__ uint64_t s_excl;
+	__shared__ uint32_t s_sbase;
+
+#ifdef DEC_PERSISTENT
+	const uint32_t nchunks = a.ctl->nchunks;
+#endif
+	uint64_t *granE = a.gran;
+	uint64_t *granS = a.gran + a.max_chunks;
+	const int lane = threadIdx.x & 63;
+	const int w = threadIdx.x >> 6;
+#ifdef DEC_PERSISTENT
+	for (;;) {
+#else
+	{
+#endif
+	if (threadIdx.x == 0)
+		s_ticket = atomicAdd(&a.ctl->ticket, 1u);
+	__syncthreads();
+	const uint32_t t = s_ticket;
+#ifdef DEC_PERSISTENT
+	if (t >= nchunks)
+		break;
+#define DEC_NEXT                                                                                    \
+	{                                                                                           \
+		__syncthreads();                                                                    \
+		continue;                                                                           \
+	}
+#else
+	if (t >= a.ctl->nchunks)
+		return;
+#define DEC_NEXT return;
+#endif
+	const ChunkDesc d = a.chunks[t];
+	const uint32_t n = d.n;
+	const uint32_t first = d.j * CHUNK;
+	const bool last = first + CHUNK >= n;
+	if (!d.cap_ok) { // not even the key bytes are there
+		if (threadIdx.x == 0) {
+			(void) lookback(granE, t, d.j, 0, last);
+			if (ZD)
+				(void) lookback(granS, t, d.j, 0, last);
+			if (last)
+				a.out_n[d.read] = CFAIL32;
+		}
+		DEC_NEXT
+	}
+	const uint8_t *in = a.in + d.out_base;
+	const uint64_t in_len = a.in_len[d.read];
+	int16_t *out = a.sig + d.sig_off;
+	const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
+	const uint64_t dlen = in_len - klen; // bytes in the data section (cap_ok: klen <= in_len)
+	const uint8_t *data = in + klen;
+	const uint32_t ws = first + w * WAVE_SAMPLES;
+
+	// ---- phase 1: keys -> which sub-tiles are not plain, and the exception count
+	uint32_t kmask = 0;
+	uint64_t etot = 0;
+	{
+		uint32_t key[CK];
+#pragma unroll
+		for (int k = 0; k < CK; k++)
+			key[k] = load_key<KEY2>(in, ws + k * SUB + lane * 8, n);
+#pragma unroll
+		for (int k = 0; k < CK; k++) {
+			const uint32_t i0 = ws + k * SUB + lane * 8;
+			const bool ragged = i0 < n && i0 + 8 > n;
+			const unsigned long long bx = __ballot(key[k] != 0);
+			const unsigned long long br = __ballot(ragged);
+			if (bx | br)
+				kmask |= 1u << k;
+			if (bx) {
+				// 3- and 4-byte codes cannot come from a 16-bit signal: poison the chain so
+				// that the read fails its length check and later offsets are out of range
+				if (KEY2 && __ballot((key[k] & 0xAAAAu) != 0))
+					etot += 1ull << 40;
+				const uint32_t inc = wave_incl_scan_dpp(key_extra_bytes<KEY2>(key[k]));
+				etot += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+			}
+		}
+	}
+	if (lane == 0)
+		s_wtot[w] = etot;
+	__syncthreads();
+	const uint64_t t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
+	if (threadIdx.x == 0)
+		s_excl = lookback(granE, t, d.j, t0 + t1 + t2 + t3, last);
+	__syncthreads();
+	const uint64_t ebefore = s_excl;
+	const uint64_t ebase = ebefore + (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
+	if (last && threadIdx.x == 0)
+		a.out_n[d.read] = ((uint64_t) n + ebefore + t0 + t1 + t2 + t3 <= dlen) ? n : CFAIL32;
+
+	// ---- phase 2: data loads of the plain sub-tiles (8 bytes per lane, any alignment)
+	uint2 dat[CK];
+	{
+		uint64_t eb = ebase;
+#pragma unroll
+		for (int k = 0; k < CK; k++) {
+			const uint32_t i0 = ws + k * SUB + lane * 8;
+			const uint32_t sub0 = ws + k * SUB;
+			uint2 dd = make_uint2(0, 0);
+			if (sub0 < n) { // uniform
+				// a sub-tile whose 8-byte windows could reach past the stream is not plain
+				if (!((kmask >> k) & 1u) && eb + sub0 + SUB + 8 > dlen)
+					kmask |= 1u << k;
+				if (!((kmask >> k) & 1u)) {
+					if (i0 < n)
+						__builtin_memcpy(&dd, data + eb + i0, 8);
+				} else {
+					const uint32_t kk = load_key<KEY2>(in, i0, n);
+					const uint32_t inc = wave_incl_scan_dpp(key_extra_bytes<KEY2>(kk));
+					eb += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+				}
+			}
+			dat[k] = dd;
+		}
+	}
+
+	// ---- phase 3: sum of the deltas in front of every lane's 8 samples (16-bit wraparound)
+	uint32_t lbase[CK / 2]; // two 16-bit bases per register
+	uint32_t wsum = 0;
+	if (ZD) {
+		uint64_t eb = ebase;
+#pragma unroll
+		for (int k = 0; k < CK; k++) {
+			const uint32_t i0 = ws + k * SUB + lane * 8;
+			uint32_t lb = 0;
+			if (ws + k * SUB < n) { // uniform
+				uint32_t v[4];
+				if (!((kmask >> k) & 1u))
+					expand8(dat[k], v);
+				else
+					eb += gather_slow<KEY2>(in, data, dlen, i0, n, eb, v);
+				uint32_t acc = 0;
+#pragma unroll
+				for (int q = 0; q < 4; q++)
+					acc = pk_add16(acc, unzz_pair(v[q]));
+				const uint32_t tot16 = (acc + (acc >> 16)) & 0xFFFFu;
+				const uint32_t inc = wave_incl_scan_dpp(tot16);
+				lb = (wsum + inc - tot16) & 0xFFFFu;
+				wsum += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+			}
+			if (k & 1)
+				lbase[k >> 1] |= lb << 16;
+			else
+				lbase[k >> 1] = lb;
+		}
+	}
+
+	// ---- sample value in front of this wave: within the chunk (LDS) and before it (look-back)
+	uint32_t sb = 0;
+	if (ZD) {
+		if (lane == 0)
+			s_wsum[w] = wsum & 0xFFFFu;
+		__syncthreads();
+		const uint32_t u0 = s_wsum[0], u1 = s_wsum[1], u2 = s_wsum[2], u3 = s_wsum[3];
+		if (threadIdx.x == 0)
+			s_sbase = (uint32_t) lookback(granS, t, d.j, (uint64_t) ((u0 + u1 + u2 + u3) & 0xFFFFu), last);
+		__syncthreads();
+		sb = s_sbase + (w > 0 ? u0 : 0u) + (w > 1 ? u1 : 0u) + (w > 2 ? u2 : 0u);
+	}
+
+	// ---- phase 4: expand again, prefix inside the lane, add the bases, store
+	{
+		uint64_t eb = ebase;
+#pragma unroll
+		for (int k = 0; k < CK; k++) {
+			const uint32_t i0 = ws + k * SUB + lane * 8;
+			if (ws + k * SUB < n) { // uniform
+				uint32_t v[4];
+				if (!((kmask >> k) & 1u))
+					expand8(dat[k], v);
+				else
+					eb += gather_slow<KEY2>(in, data, dlen, i0, n, eb, v);
+				if (ZD) {
+#pragma unroll
+					for (int q = 0; q < 4; q++)
+						v[q] = unzz_pair(v[q]);
+					(void) lane_prefix8(v);
+					const uint32_t b16 = (sb + ((lbase[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)) & 0xFFFFu;
+					const uint32_t b2 = b16 | (b16 << 16);
+#pragma unroll
+					for (int q = 0; q < 4; q++)
+						v[q] = pk_add16(v[q], b2);
+				}
+				if (i0 + 8 <= n) {
+					*reinterpret_cast<uint4 *>(out + i0) = make_uint4(v[0], v[1], v[2], v[3]);
+				} else if (i0 < n) {
+#pragma unroll
+					for (uint32_t q = 0; q < 8; q++)
+						if (q < n - i0)
+							out[i0 + q] = (int16_t) (v[q >> 1] >> (16 * (q & 1)));
+				}
+			}
+		}
+	}
+#ifdef DEC_PERSISTENT
+	__syncthreads(); // every wave has read s_ticket before thread 0 overwrites it
+#endif
+	} // ticket loop / single chunk
+}
+
 // ------------------------------------------------------------------ launchers
 
 template <bool KEY2, bool ZD>
@@ -393,10 +724,31 @@ void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStr
 		run_encode<false, false>(a, s);
 }
 
+template <bool KEY2, bool ZD>
+static void run_decode(const DecodeArgs &a, hipStream_t s)
+{
+	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
+	hipLaunchKernelGGL((k_chunk_prep<true, KEY2>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
+			   a.nsamp, a.in_off, a.in_len, a.nreads, a.chunks, a.gran, a.ctl, a.max_chunks,
+			   (uint64_t *) nullptr, a.out_n);
+#ifdef DEC_PERSISTENT
+	const uint32_t grid = a.max_chunks < EXP_GRID ? a.max_chunks : EXP_GRID;
+#else
+	const uint32_t grid = a.max_chunks; // one chunk per workgroup; surplus workgroups exit at once
+#endif
+	hipLaunchKernelGGL((k_svb_decode_chunked<KEY2, ZD>), dim3(grid), dim3(CWG), 0, s, a);
+}
+
 void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s)
 {
-	// v2 decode lands next; the v1 kernel is the decode path for now
-	launch_svb_decode(a, key2bit, zd, s);
+	if (!a.nreads || !a.max_chunks)
+		return;
+	if (key2bit)
+		run_decode<true, true>(a, s);
+	else if (zd)
+		run_decode<false, true>(a, s);
+	else
+		run_decode<false, false>(a, s);
 }
 
 } // namespace ph
