@@ -82,31 +82,58 @@ __device__ __forceinline__ uint64_t gran_load(uint64_t *g)
 	return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Decoupled look-back (one lane): publish this chunk's aggregate, sum the aggregates of the
-// chunks before it in the same read, publish the inclusive prefix.  `t` = this chunk's
-// ticket, j = its index in the read (chunk t-j is the read's first).  Returns the exclusive
-// prefix.  `last`: no chunk of this read follows, nothing needs publishing.
+// Decoupled look-back, executed by ONE WAVE (all 64 lanes call it): publish this chunk's
+// aggregate, sum the aggregates of the chunks before it in the same read - 64 granules per
+// round trip, nearest first - and publish the inclusive prefix.  `t` = this chunk's ticket,
+// j = its index in the read (chunk t-j is the read's first and always publishes a prefix).
+// Returns the exclusive prefix (same value in every lane).  `last`: no chunk of this read
+// follows, nothing needs publishing.
 __device__ __forceinline__ uint64_t lookback(uint64_t *gran, uint32_t t, uint32_t j, uint64_t mine, bool last)
 {
+	const uint32_t lane = threadIdx.x & 63;
 	if (j == 0) {
-		if (!last)
+		if (!last && lane == 0)
 			gran_store(gran + t, G_P | mine);
 		return 0;
 	}
-	if (!last)
+	if (!last && lane == 0)
 		gran_store(gran + t, G_A | mine);
 	uint64_t sum = 0;
-	for (uint32_t i = t - 1;; i--) {
-		uint64_t g = gran_load(gran + i);
-		while ((g >> 62) == 0) {
-			__builtin_amdgcn_s_sleep(2);
-			g = gran_load(gran + i);
+	uint32_t done = 0; // predecessors already summed
+	for (;;) {
+		// lane l looks at predecessor number done + l (0 = the chunk right before this one)
+		const uint32_t idx = done + lane;
+		const bool want = idx < j;
+		uint64_t g = 0;
+		if (want)
+			g = gran_load(gran + (t - 1 - idx));
+		const unsigned long long pmask = __ballot(want && (g >> 62) == 2);
+		const unsigned long long zmask = __ballot(want && (g >> 62) == 0);
+		// usable lanes: everything nearer than the first unpublished granule, up to and
+		// including the first prefix
+		uint32_t stop = 64;
+		if (zmask)
+			stop = (uint32_t) __builtin_ctzll(zmask);
+		uint32_t firstp = 64;
+		if (pmask)
+			firstp = (uint32_t) __builtin_ctzll(pmask);
+		const bool have_p = firstp < stop;
+		const uint32_t take = have_p ? firstp + 1 : stop; // lanes [0, take) are added
+		uint64_t v = (lane < take) ? (g & G_MASK) : 0;
+#pragma unroll
+		for (int dd = 32; dd >= 1; dd >>= 1) {
+			const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) v, dd, 64);
+			const uint32_t hi = (uint32_t) __shfl_xor((int) (uint32_t) (v >> 32), dd, 64);
+			v += ((uint64_t) hi << 32) | lo;
 		}
-		sum += g & G_MASK;
-		if ((g >> 62) == 2)
+		sum += v;
+		done += take;
+		if (have_p || done >= j)
 			break;
+		if (take == 0)
+			__builtin_amdgcn_s_sleep(2);
 	}
-	if (!last)
+	if (!last && lane == 0)
 		gran_store(gran + t, G_P | (sum + mine));
 	return sum;
 }
@@ -195,9 +222,9 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 	const int w = threadIdx.x >> 6;
 
 	if (!d.cap_ok) { // slot smaller than the worst case of the format: fail the read
-		if (threadIdx.x == 0) {
+		if (threadIdx.x < 64) {
 			(void) lookback(a.gran, t, d.j, 0, last);
-			if (last)
+			if (last && threadIdx.x == 0)
 				a.out_len[d.read] = CFAIL64;
 		}
 		__syncthreads(); // every wave has read s_ticket before thread 0 overwrites it
@@ -272,13 +299,11 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 		s_wtot[w] = etot;
 	__syncthreads();
 	const uint32_t t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
-#ifdef EXP_NO_LOOKBACK
-	if (threadIdx.x == 0)
-		s_excl = 0;
-#else
-	if (threadIdx.x == 0)
-		s_excl = lookback(a.gran, t, d.j, (uint64_t) t0 + t1 + t2 + t3, last);
-#endif
+	if (w == 0) {
+		const uint64_t e = lookback(a.gran, t, d.j, (uint64_t) t0 + t1 + t2 + t3, last);
+		if (lane == 0)
+			s_excl = e;
+	}
 	__syncthreads();
 	const uint64_t ebefore = s_excl;
 	uint64_t ebase = ebefore + (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
@@ -530,11 +555,11 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 	const uint32_t first = d.j * CHUNK;
 	const bool last = first + CHUNK >= n;
 	if (!d.cap_ok) { // not even the key bytes are there
-		if (threadIdx.x == 0) {
+		if (threadIdx.x < 64) {
 			(void) lookback(granE, t, d.j, 0, last);
 			if (ZD)
 				(void) lookback(granS, t, d.j, 0, last);
-			if (last)
+			if (last && threadIdx.x == 0)
 				a.out_n[d.read] = CFAIL32;
 		}
 		DEC_NEXT
@@ -577,8 +602,15 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 		s_wtot[w] = etot;
 	__syncthreads();
 	const uint64_t t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
-	if (threadIdx.x == 0)
-		s_excl = lookback(granE, t, d.j, t0 + t1 + t2 + t3, last);
+	if (w == 0) {
+#ifdef DEXP_NO_LB_E
+		const uint64_t e = 0;
+#else
+		const uint64_t e = lookback(granE, t, d.j, t0 + t1 + t2 + t3, last);
+#endif
+		if (lane == 0)
+			s_excl = e;
+	}
 	__syncthreads();
 	const uint64_t ebefore = s_excl;
 	const uint64_t ebase = ebefore + (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
@@ -649,8 +681,15 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 			s_wsum[w] = wsum & 0xFFFFu;
 		__syncthreads();
 		const uint32_t u0 = s_wsum[0], u1 = s_wsum[1], u2 = s_wsum[2], u3 = s_wsum[3];
-		if (threadIdx.x == 0)
-			s_sbase = (uint32_t) lookback(granS, t, d.j, (uint64_t) ((u0 + u1 + u2 + u3) & 0xFFFFu), last);
+		if (w == 0) {
+#ifdef DEXP_NO_LB_S
+			const uint32_t sv = 0;
+#else
+			const uint32_t sv = (uint32_t) lookback(granS, t, d.j, (uint64_t) ((u0 + u1 + u2 + u3) & 0xFFFFu), last);
+#endif
+			if (lane == 0)
+				s_sbase = sv;
+		}
 		__syncthreads();
 		sb = s_sbase + (w > 0 ? u0 : 0u) + (w > 1 ? u1 : 0u) + (w > 2 ? u2 : 0u);
 	}
