@@ -80,7 +80,7 @@ struct Ctx {
 	hipStream_t user = nullptr;
 	bool use_user = false;
 	// scratch shared by both modes
-	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl;
+	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk;
 	int use_v1 = -1; // PRESS_HIP_V1=1 selects the one-workgroup-per-read svb kernels (A/B)
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn;
@@ -241,7 +241,7 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 	if (is_svb(method)) {
 		const size_t mc = max_chunks_of(total_samples, nreads);
 		if (g.chunks.reserve(mc * sizeof(ChunkDesc)) || g.gran.reserve(2 * mc * sizeof(uint64_t)) ||
-		    g.ctl.reserve(sizeof(ChunkCtl)))
+		    g.ctl.reserve(sizeof(ChunkCtl)) || g.first_chunk.reserve(((size_t) nreads + 1) * 4))
 			return PRESS_HIP_EHIP;
 	}
 	if (is_ex(method)) {
@@ -307,7 +307,7 @@ extern "C" void press_hip_shutdown(void)
 		return;
 	(void) hipSetDevice(g.device);
 	(void) hipStreamSynchronize(g.own);
-	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.chunks, &g.gran, &g.ctl, &g.sig, &g.off, &g.nsamp,
+	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.chunks, &g.gran, &g.ctl, &g.first_chunk, &g.sig, &g.off, &g.nsamp,
 			  &g.arena, &g.arena_off, &g.lens, &g.lens2, &g.outn };
 	for (DevBuf *b : all)
 		b->release();
@@ -525,6 +525,7 @@ extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint
 	a.chunks = (ChunkDesc *) g.chunks.p;
 	a.gran = (uint64_t *) g.gran.p;
 	a.ctl = (ChunkCtl *) g.ctl.p;
+	a.first_chunk = (uint32_t *) g.first_chunk.p;
 	a.max_chunks = max_chunks_of(total_samples, nreads);
 
 	if (device_resident) {

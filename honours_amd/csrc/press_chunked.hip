@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 						    const uint64_t *slot_off, const uint64_t *in_len,
 						    uint32_t nreads, ChunkDesc *chunks, uint64_t *gran,
 						    ChunkCtl *ctl, uint32_t max_chunks, uint64_t *out_len,
-						    uint32_t *out_n)
+						    uint32_t *out_n, uint32_t *first_chunk)
 {
 	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
 	uint32_t n = 0, nch = 0;
@@ -178,6 +178,8 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 			out_n[r] = 0;
 	}
 	const uint64_t o = off[r];
+	if (DEC)
+		first_chunk[r] = first;
 	for (uint32_t j = 0; j < nch; j++) {
 		if (first + j >= max_chunks)
 			break; // cannot happen: max_chunks bounds the sum
@@ -188,10 +190,11 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 		d.j = j;
 		d.read = r;
 		d.cap_ok = ok;
+		d.ebefore = 0;
+		d.ecnt[0] = d.ecnt[1] = d.ecnt[2] = d.ecnt[3] = 0;
+		d.kmask[0] = d.kmask[1] = d.kmask[2] = d.kmask[3] = 0;
 		chunks[first + j] = d;
 		gran[first + j] = 0;
-		if (DEC)
-			gran[max_chunks + first + j] = 0;
 	}
 }
 
@@ -512,57 +515,105 @@ __device__ __forceinline__ void expand8(uint2 dd, uint32_t v[4])
 	v[3] = __builtin_amdgcn_perm(0, dd.y, 0x0c030c02);
 }
 
+// ---- key scan: the exception counts depend on the key bytes only (n/8 bytes, 4 % of the
+// stream), so they are settled by two tiny kernels before any data is touched; the main
+// kernel then starts its data loads straight from the chunk descriptor.
+
+// One workgroup per chunk: per wave quarter, which sub-tiles are not plain and how many
+// extra data bytes (exceptions) the quarter holds.
+template <bool KEY2>
+__global__ __launch_bounds__(CWG) void k_svb_keyscan(DecodeArgs a)
+{
+	const uint32_t c = blockIdx.x;
+	if (c >= a.ctl->nchunks)
+		return;
+	ChunkDesc *dp = a.chunks + c;
+	if (!dp->cap_ok)
+		return;
+	const uint32_t n = dp->n;
+	const uint8_t *in = a.in + dp->out_base;
+	const int lane = threadIdx.x & 63;
+	const int w = threadIdx.x >> 6;
+	const uint32_t ws = dp->j * CHUNK + w * WAVE_SAMPLES;
+	uint32_t key[CK];
+#pragma unroll
+	for (int k = 0; k < CK; k++)
+		key[k] = load_key<KEY2>(in, ws + k * SUB + lane * 8, n);
+	uint32_t kmask = 0;
+	uint64_t etot = 0;
+#pragma unroll
+	for (int k = 0; k < CK; k++) {
+		const uint32_t i0 = ws + k * SUB + lane * 8;
+		const bool ragged = i0 < n && i0 + 8 > n;
+		const unsigned long long bx = __ballot(key[k] != 0);
+		const unsigned long long br = __ballot(ragged);
+		if (bx | br)
+			kmask |= 1u << k;
+		if (bx) {
+			// 3- and 4-byte codes cannot come from a 16-bit signal: poison the count so that
+			// the read fails its length check and its offsets fall out of range
+			if (KEY2 && __ballot((key[k] & 0xAAAAu) != 0))
+				etot += 1u << 30;
+			const uint32_t inc = wave_incl_scan_dpp(key_extra_bytes<KEY2>(key[k]));
+			etot += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+		}
+	}
+	if (lane == 0) {
+		dp->ecnt[w] = (uint32_t) (etot > 0xFFFFFFFFull ? 0xFFFFFFFFull : etot);
+		dp->kmask[w] = (uint16_t) kmask;
+	}
+}
+
+// One thread per read: exclusive prefix of the chunk counts, and the verdict on the stream
+// length (decode.hpp:23 consumes klen + n + #exceptions bytes).
+template <bool KEY2>
+__global__ __launch_bounds__(256) void k_svb_keyprefix(DecodeArgs a)
+{
+	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r >= a.nreads)
+		return;
+	const uint32_t n = a.nsamp[r];
+	if (n == 0)
+		return; // out_n[r] = 0 written by k_chunk_prep
+	const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
+	const uint64_t in_len = a.in_len[r];
+	if (klen > in_len) {
+		a.out_n[r] = CFAIL32;
+		return;
+	}
+	ChunkDesc *dp = a.chunks + a.first_chunk[r];
+	const uint32_t nch = (n + CHUNK - 1) / CHUNK;
+	uint64_t e = 0;
+	for (uint32_t j = 0; j < nch; j++) {
+		dp[j].ebefore = e;
+		e += (uint64_t) dp[j].ecnt[0] + dp[j].ecnt[1] + dp[j].ecnt[2] + dp[j].ecnt[3];
+	}
+	a.out_n[r] = ((uint64_t) klen + n + e <= in_len) ? n : CFAIL32;
+}
+
 template <bool KEY2, bool ZD>
 __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 {
 	__shared__ uint32_t s_ticket;
-	__shared__ uint64_t s_wtot[4];
 	__shared__ uint32_t s_wsum[4];
-	__shared__ uint64_t s_excl;
 	__shared__ uint32_t s_sbase;
 
-#ifdef DEC_PERSISTENT
-	const uint32_t nchunks = a.ctl->nchunks;
-#endif
-	uint64_t *granE = a.gran;
-	uint64_t *granS = a.gran + a.max_chunks;
 	const int lane = threadIdx.x & 63;
 	const int w = threadIdx.x >> 6;
-#ifdef DEC_PERSISTENT
-	for (;;) {
-#else
-	{
-#endif
 	if (threadIdx.x == 0)
 		s_ticket = atomicAdd(&a.ctl->ticket, 1u);
 	__syncthreads();
 	const uint32_t t = s_ticket;
-#ifdef DEC_PERSISTENT
-	if (t >= nchunks)
-		break;
-#define DEC_NEXT                                                                                    \
-	{                                                                                           \
-		__syncthreads();                                                                    \
-		continue;                                                                           \
-	}
-#else
 	if (t >= a.ctl->nchunks)
 		return;
-#define DEC_NEXT return;
-#endif
 	const ChunkDesc d = a.chunks[t];
 	const uint32_t n = d.n;
 	const uint32_t first = d.j * CHUNK;
 	const bool last = first + CHUNK >= n;
-	if (!d.cap_ok) { // not even the key bytes are there
-		if (threadIdx.x < 64) {
-			(void) lookback(granE, t, d.j, 0, last);
-			if (ZD)
-				(void) lookback(granS, t, d.j, 0, last);
-			if (last && threadIdx.x == 0)
-				a.out_n[d.read] = CFAIL32;
-		}
-		DEC_NEXT
+	if (!d.cap_ok) { // not even the key bytes are there (out_n: k_svb_keyprefix)
+		if (ZD && threadIdx.x < 64)
+			(void) lookback(a.gran, t, d.j, 0, last);
+		return;
 	}
 	const uint8_t *in = a.in + d.out_base;
 	const uint64_t in_len = a.in_len[d.read];
@@ -571,53 +622,11 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 	const uint64_t dlen = in_len - klen; // bytes in the data section (cap_ok: klen <= in_len)
 	const uint8_t *data = in + klen;
 	const uint32_t ws = first + w * WAVE_SAMPLES;
+	uint32_t kmask = d.kmask[w];
+	const uint64_t ebase = d.ebefore + (w > 0 ? d.ecnt[0] : 0u) + (w > 1 ? d.ecnt[1] : 0u) +
+			       (w > 2 ? d.ecnt[2] : 0u);
 
-	// ---- phase 1: keys -> which sub-tiles are not plain, and the exception count
-	uint32_t kmask = 0;
-	uint64_t etot = 0;
-	{
-		uint32_t key[CK];
-#pragma unroll
-		for (int k = 0; k < CK; k++)
-			key[k] = load_key<KEY2>(in, ws + k * SUB + lane * 8, n);
-#pragma unroll
-		for (int k = 0; k < CK; k++) {
-			const uint32_t i0 = ws + k * SUB + lane * 8;
-			const bool ragged = i0 < n && i0 + 8 > n;
-			const unsigned long long bx = __ballot(key[k] != 0);
-			const unsigned long long br = __ballot(ragged);
-			if (bx | br)
-				kmask |= 1u << k;
-			if (bx) {
-				// 3- and 4-byte codes cannot come from a 16-bit signal: poison the chain so
-				// that the read fails its length check and later offsets are out of range
-				if (KEY2 && __ballot((key[k] & 0xAAAAu) != 0))
-					etot += 1ull << 40;
-				const uint32_t inc = wave_incl_scan_dpp(key_extra_bytes<KEY2>(key[k]));
-				etot += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
-			}
-		}
-	}
-	if (lane == 0)
-		s_wtot[w] = etot;
-	__syncthreads();
-	const uint64_t t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
-	if (w == 0) {
-#ifdef DEXP_NO_LB_E
-		const uint64_t e = 0;
-#else
-		const uint64_t e = lookback(granE, t, d.j, t0 + t1 + t2 + t3, last);
-#endif
-		if (lane == 0)
-			s_excl = e;
-	}
-	__syncthreads();
-	const uint64_t ebefore = s_excl;
-	const uint64_t ebase = ebefore + (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
-	if (last && threadIdx.x == 0)
-		a.out_n[d.read] = ((uint64_t) n + ebefore + t0 + t1 + t2 + t3 <= dlen) ? n : CFAIL32;
-
-	// ---- phase 2: data loads of the plain sub-tiles (8 bytes per lane, any alignment)
+	// ---- phase 1: data loads of the plain sub-tiles (8 bytes per lane, any alignment)
 	uint2 dat[CK];
 	{
 		uint64_t eb = ebase;
@@ -643,7 +652,7 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 		}
 	}
 
-	// ---- phase 3: sum of the deltas in front of every lane's 8 samples (16-bit wraparound)
+	// ---- phase 2: sum of the deltas in front of every lane's 8 samples (16-bit wraparound)
 	uint32_t lbase[CK / 2]; // two 16-bit bases per register
 	uint32_t wsum = 0;
 	if (ZD) {
@@ -682,11 +691,7 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 		__syncthreads();
 		const uint32_t u0 = s_wsum[0], u1 = s_wsum[1], u2 = s_wsum[2], u3 = s_wsum[3];
 		if (w == 0) {
-#ifdef DEXP_NO_LB_S
-			const uint32_t sv = 0;
-#else
-			const uint32_t sv = (uint32_t) lookback(granS, t, d.j, (uint64_t) ((u0 + u1 + u2 + u3) & 0xFFFFu), last);
-#endif
+			const uint32_t sv = (uint32_t) lookback(a.gran, t, d.j, (uint64_t) ((u0 + u1 + u2 + u3) & 0xFFFFu), last);
 			if (lane == 0)
 				s_sbase = sv;
 		}
@@ -694,7 +699,7 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 		sb = s_sbase + (w > 0 ? u0 : 0u) + (w > 1 ? u1 : 0u) + (w > 2 ? u2 : 0u);
 	}
 
-	// ---- phase 4: expand again, prefix inside the lane, add the bases, store
+	// ---- phase 3: expand again, prefix inside the lane, add the bases, store
 	{
 		uint64_t eb = ebase;
 #pragma unroll
@@ -728,10 +733,6 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 			}
 		}
 	}
-#ifdef DEC_PERSISTENT
-	__syncthreads(); // every wave has read s_ticket before thread 0 overwrites it
-#endif
-	} // ticket loop / single chunk
 }
 
 // ------------------------------------------------------------------ launchers
@@ -742,7 +743,7 @@ static void run_encode(const BatchArgs &a, hipStream_t s)
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL((k_chunk_prep<false, KEY2>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
 			   a.nsamp, a.out_off, (const uint64_t *) nullptr, a.nreads, a.chunks, a.gran, a.ctl,
-			   a.max_chunks, a.out_len, (uint32_t *) nullptr);
+			   a.max_chunks, a.out_len, (uint32_t *) nullptr, (uint32_t *) nullptr);
 	// persistent grid: enough workgroups to fill the chip twice over (4 resident per CU)
 #ifndef EXP_GRID
 #define EXP_GRID 2048u
@@ -769,13 +770,11 @@ static void run_decode(const DecodeArgs &a, hipStream_t s)
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL((k_chunk_prep<true, KEY2>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
 			   a.nsamp, a.in_off, a.in_len, a.nreads, a.chunks, a.gran, a.ctl, a.max_chunks,
-			   (uint64_t *) nullptr, a.out_n);
-#ifdef DEC_PERSISTENT
-	const uint32_t grid = a.max_chunks < EXP_GRID ? a.max_chunks : EXP_GRID;
-#else
-	const uint32_t grid = a.max_chunks; // one chunk per workgroup; surplus workgroups exit at once
-#endif
-	hipLaunchKernelGGL((k_svb_decode_chunked<KEY2, ZD>), dim3(grid), dim3(CWG), 0, s, a);
+			   (uint64_t *) nullptr, a.out_n, a.first_chunk);
+	// surplus workgroups (max_chunks bounds the real count from above) exit at once
+	hipLaunchKernelGGL((k_svb_keyscan<KEY2>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
+	hipLaunchKernelGGL((k_svb_keyprefix<KEY2>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a);
+	hipLaunchKernelGGL((k_svb_decode_chunked<KEY2, ZD>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
 }
 
 void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s)

@@ -40,14 +40,19 @@ struct HuffDev {
 // ---- chunked (v2) svb kernels: a read is cut into chunks of CHUNK samples, one workgroup
 // per chunk; chunks of a read are chained by a decoupled look-back over 8-byte granules.
 constexpr uint32_t CHUNK = 32768;           // samples per chunk: 4 waves x 16 sub-tiles x 512
-struct ChunkDesc {                          // written by k_chunk_prep, one per chunk (32 bytes)
+struct ChunkDesc {                          // written by k_chunk_prep, one per chunk (64 bytes)
 	uint64_t sig_off;   // sample offset of the READ in sig
-	uint64_t out_base;  // byte offset of the read's slot in the arena
+	uint64_t out_base;  // byte offset of the read's slot (encode) / stream (decode) in the arena
 	uint32_t n;         // samples in the read
 	uint32_t j;         // chunk index within the read
 	uint32_t read;      // read index
 	uint32_t cap_ok;    // slot large enough for the worst case of the format
+	// decode only, filled by k_svb_keyscan / k_svb_keyprefix:
+	uint64_t ebefore;   // exceptions (extra data bytes) in front of this chunk
+	uint32_t ecnt[4];   // exceptions in each wave's quarter of the chunk
+	uint16_t kmask[4];  // per wave: sub-tiles that are not plain (exception or ragged tail)
 };
+static_assert(sizeof(ChunkDesc) == 64, "ChunkDesc is one 64-byte line");
 struct ChunkCtl {                           // device control block; every word on its own 128-B line
 	uint32_t ticket;    // next chunk to hand out (atomic)
 	uint32_t pad0[31];
@@ -93,8 +98,9 @@ struct DecodeArgs {
 	uint32_t nreads;
 	// chunked kernels
 	ChunkDesc *chunks;
-	uint64_t *gran;           // [2 * max_chunks]: byte-offset chain, then sample-value chain
+	uint64_t *gran;           // [max_chunks] look-back granules of the sample-value chain
 	ChunkCtl *ctl;
+	uint32_t *first_chunk;    // [nreads] id of the first chunk of read r
 	uint32_t max_chunks;
 };
 
