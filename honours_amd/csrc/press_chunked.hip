@@ -43,6 +43,13 @@ constexpr uint32_t CFAIL32 = 0xFFFFFFFFu;
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
+// wave-uniform values: tell the compiler (scalar registers, scalar branches)
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v)
+{
+	return ((uint64_t) uni((uint32_t) (v >> 32)) << 32) | uni((uint32_t) v);
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v)
 {
 	const int lane = threadIdx.x & 63;
@@ -138,6 +145,23 @@ __device__ __forceinline__ uint64_t lookback(uint64_t *gran, uint32_t t, uint32_
 	return sum;
 }
 
+// the fields of a chunk descriptor as wave-uniform (scalar) values
+struct ChunkU {
+	uint64_t sig_off, out_base;
+	uint32_t n, j, read, cap_ok;
+};
+__device__ __forceinline__ ChunkU load_chunk(const ChunkDesc *dp)
+{
+	ChunkU c;
+	c.sig_off = uni64(dp->sig_off);
+	c.out_base = uni64(dp->out_base);
+	c.n = uni(dp->n);
+	c.j = uni(dp->j);
+	c.read = uni(dp->read);
+	c.cap_ok = uni(dp->cap_ok);
+	return c;
+}
+
 // ------------------------------------------------------------------ chunk table
 
 // One thread per read: a wave adds up its reads' chunk counts, takes a contiguous range of
@@ -209,20 +233,20 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 
 	// persistent workgroups: chunks are handed out in ticket order (what makes the
 	// look-back deadlock free).  (Fetching the next ticket early was measured slower.)
-	const uint32_t nchunks = a.ctl->nchunks;
+	const uint32_t nchunks = uni(a.ctl->nchunks);
 	for (;;) {
 	if (threadIdx.x == 0)
 		s_ticket = atomicAdd(&a.ctl->ticket, 1u);
 	__syncthreads();
-	const uint32_t t = s_ticket;
+	const uint32_t t = uni(s_ticket);
 	if (t >= nchunks)
 		break;
-	const ChunkDesc d = a.chunks[t];
+	const ChunkU d = load_chunk(a.chunks + t);
 	const uint32_t n = d.n;
 	const uint32_t first = d.j * CHUNK;          // first sample of the chunk within the read
 	const bool last = first + CHUNK >= n;
 	const int lane = threadIdx.x & 63;
-	const int w = threadIdx.x >> 6;
+	const int w = (int) uni(threadIdx.x >> 6);
 
 	if (!d.cap_ok) { // slot smaller than the worst case of the format: fail the read
 		if (threadIdx.x < 64) {
@@ -301,14 +325,14 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 	if (lane == 0)
 		s_wtot[w] = etot;
 	__syncthreads();
-	const uint32_t t0 = s_wtot[0], t1 = s_wtot[1], t2 = s_wtot[2], t3 = s_wtot[3];
+	const uint32_t t0 = uni(s_wtot[0]), t1 = uni(s_wtot[1]), t2 = uni(s_wtot[2]), t3 = uni(s_wtot[3]);
 	if (w == 0) {
 		const uint64_t e = lookback(a.gran, t, d.j, (uint64_t) t0 + t1 + t2 + t3, last);
 		if (lane == 0)
 			s_excl = e;
 	}
 	__syncthreads();
-	const uint64_t ebefore = s_excl;
+	const uint64_t ebefore = uni64(s_excl);
 	uint64_t ebase = ebefore + (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
 	if (last && threadIdx.x == 0)
 		a.out_len[d.read] = (uint64_t) klen + n + ebefore + t0 + t1 + t2 + t3;
@@ -533,7 +557,7 @@ __global__ __launch_bounds__(CWG) void k_svb_keyscan(DecodeArgs a)
 	const uint32_t n = dp->n;
 	const uint8_t *in = a.in + dp->out_base;
 	const int lane = threadIdx.x & 63;
-	const int w = threadIdx.x >> 6;
+	const int w = (int) uni(threadIdx.x >> 6);
 	const uint32_t ws = dp->j * CHUNK + w * WAVE_SAMPLES;
 	uint32_t key[CK];
 #pragma unroll
@@ -599,14 +623,15 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 	__shared__ uint32_t s_sbase;
 
 	const int lane = threadIdx.x & 63;
-	const int w = threadIdx.x >> 6;
+	const int w = (int) uni(threadIdx.x >> 6);
 	if (threadIdx.x == 0)
 		s_ticket = atomicAdd(&a.ctl->ticket, 1u);
 	__syncthreads();
-	const uint32_t t = s_ticket;
+	const uint32_t t = uni(s_ticket);
 	if (t >= a.ctl->nchunks)
 		return;
-	const ChunkDesc d = a.chunks[t];
+	const ChunkDesc *dp = a.chunks + t;
+	const ChunkU d = load_chunk(dp);
 	const uint32_t n = d.n;
 	const uint32_t first = d.j * CHUNK;
 	const bool last = first + CHUNK >= n;
@@ -616,15 +641,15 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 		return;
 	}
 	const uint8_t *in = a.in + d.out_base;
-	const uint64_t in_len = a.in_len[d.read];
+	const uint64_t in_len = uni64(a.in_len[d.read]);
 	int16_t *out = a.sig + d.sig_off;
 	const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
 	const uint64_t dlen = in_len - klen; // bytes in the data section (cap_ok: klen <= in_len)
 	const uint8_t *data = in + klen;
 	const uint32_t ws = first + w * WAVE_SAMPLES;
-	uint32_t kmask = d.kmask[w];
-	const uint64_t ebase = d.ebefore + (w > 0 ? d.ecnt[0] : 0u) + (w > 1 ? d.ecnt[1] : 0u) +
-			       (w > 2 ? d.ecnt[2] : 0u);
+	uint32_t kmask = uni(dp->kmask[w]);
+	const uint32_t e0 = uni(dp->ecnt[0]), e1 = uni(dp->ecnt[1]), e2 = uni(dp->ecnt[2]);
+	const uint64_t ebase = uni64(dp->ebefore) + (w > 0 ? e0 : 0u) + (w > 1 ? e1 : 0u) + (w > 2 ? e2 : 0u);
 
 	// ---- phase 1: data loads of the plain sub-tiles (8 bytes per lane, any alignment)
 	uint2 dat[CK];
@@ -689,14 +714,14 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 		if (lane == 0)
 			s_wsum[w] = wsum & 0xFFFFu;
 		__syncthreads();
-		const uint32_t u0 = s_wsum[0], u1 = s_wsum[1], u2 = s_wsum[2], u3 = s_wsum[3];
+		const uint32_t u0 = uni(s_wsum[0]), u1 = uni(s_wsum[1]), u2 = uni(s_wsum[2]), u3 = uni(s_wsum[3]);
 		if (w == 0) {
 			const uint32_t sv = (uint32_t) lookback(a.gran, t, d.j, (uint64_t) ((u0 + u1 + u2 + u3) & 0xFFFFu), last);
 			if (lane == 0)
 				s_sbase = sv;
 		}
 		__syncthreads();
-		sb = s_sbase + (w > 0 ? u0 : 0u) + (w > 1 ? u1 : 0u) + (w > 2 ? u2 : 0u);
+		sb = uni(s_sbase) + (w > 0 ? u0 : 0u) + (w > 1 ? u1 : 0u) + (w > 2 ? u2 : 0u);
 	}
 
 	// ---- phase 3: expand again, prefix inside the lane, add the bases, store
