@@ -615,12 +615,51 @@ __global__ __launch_bounds__(256) void k_svb_keyprefix(DecodeArgs a)
 	a.out_n[r] = ((uint64_t) klen + n + e <= in_len) ? n : CFAIL32;
 }
 
+#ifdef DEC_STAMPS
+// diagnostic build only: per-chunk phase timestamps (s_memtime), read back by tools
+__device__ uint64_t g_stamps[65536 * 8];
+#define STAMP(i)                                                                         \
+	do {                                                                             \
+		if (threadIdx.x == 0 && t < 65536)                                       \
+			g_stamps[t * 8 + (i)] = __builtin_amdgcn_s_memtime();             \
+	} while (0)
+extern "C" int press_hip_debug_stamps(uint64_t *dst, uint32_t nwords)
+{
+	return (int) hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), (size_t) nwords * 8);
+}
+#else
+#define STAMP(i)
+#endif
+
+// make the LDS writes of this wave visible to its other lanes (DS ops of a wave execute in
+// order; this only stops the compiler from moving them)
+__device__ __forceinline__ void wave_lds_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Main decode kernel.  Structure per wave quarter (16 sub-tiles):
+//   * the plain sub-tiles (no exception, no ragged tail, not at the end of the stream) are
+//     handled by fully unrolled loops that contain no load except their own 8-byte data
+//     load - so the compiler needs no conservative s_waitcnt between the 16 stores;
+//   * the few other sub-tiles go through ROLLED loops over the set bits of `kmask`
+//     (byte-wise gather, one copy of the code);
+//   * both write their per-lane and per-sub-tile running sums to a small wave-private LDS
+//     table, which also frees the registers a per-sub-tile array would take.
 template <bool KEY2, bool ZD>
 __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 {
+#ifdef DEC_STAMPS
+	const uint64_t t_start = __builtin_amdgcn_s_memtime();
+#endif
 	__shared__ uint32_t s_ticket;
 	__shared__ uint32_t s_wsum[4];
 	__shared__ uint32_t s_sbase;
+	__shared__ uint16_t s_xl[4][CK][64];  // delta sum in front of the lane, within its sub-tile
+	__shared__ uint32_t s_sub[4][CK];     // per sub-tile: exception count, later delta total / base
+	__shared__ uint32_t s_epre[4][CK];    // exceptions of the wave's earlier sub-tiles
 
 	const int lane = threadIdx.x & 63;
 	const int w = (int) uni(threadIdx.x >> 6);
@@ -630,6 +669,11 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 	const uint32_t t = uni(s_ticket);
 	if (t >= a.ctl->nchunks)
 		return;
+#ifdef DEC_STAMPS
+	if (threadIdx.x == 0 && t < 65536)
+		g_stamps[t * 8 + 0] = t_start;
+#endif
+	STAMP(1);
 	const ChunkDesc *dp = a.chunks + t;
 	const ChunkU d = load_chunk(dp);
 	const uint32_t n = d.n;
@@ -647,73 +691,109 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 	const uint64_t dlen = in_len - klen; // bytes in the data section (cap_ok: klen <= in_len)
 	const uint8_t *data = in + klen;
 	const uint32_t ws = first + w * WAVE_SAMPLES;
-	uint32_t kmask = uni(dp->kmask[w]);
-	const uint32_t e0 = uni(dp->ecnt[0]), e1 = uni(dp->ecnt[1]), e2 = uni(dp->ecnt[2]);
+	const uint32_t e0 = uni(dp->ecnt[0]), e1 = uni(dp->ecnt[1]), e2 = uni(dp->ecnt[2]), e3 = uni(dp->ecnt[3]);
+	const uint32_t ew = w == 0 ? e0 : w == 1 ? e1 : w == 2 ? e2 : e3;
 	const uint64_t ebase = uni64(dp->ebefore) + (w > 0 ? e0 : 0u) + (w > 1 ? e1 : 0u) + (w > 2 ? e2 : 0u);
+	// sub-tiles of this wave that exist, and those that are not plain; a sub-tile whose
+	// 8-byte windows could reach past the end of the stream is not plain either
+	const uint32_t nsub = ws >= n ? 0u : min((uint32_t) CK, (n - ws + SUB - 1) / SUB);
+	const uint32_t live = nsub >= 32 ? ~0u : ((1u << nsub) - 1u);
+	uint32_t kmask = uni(dp->kmask[w]) & live;
+#pragma unroll
+	for (int k = 0; k < CK; k++)
+		if (((live >> k) & 1u) && ebase + ew + ws + k * SUB + SUB + 8 > dlen)
+			kmask |= 1u << k;
+	const uint32_t plain = live & ~kmask;
+	STAMP(2);
+
+	// ---- exceptions of the non-plain sub-tiles -> data offset of every sub-tile
+	if (lane < CK)
+		s_sub[w][lane] = 0;
+	wave_lds_sync();
+	for (uint32_t m = kmask; m; m &= m - 1) {
+		const uint32_t k = (uint32_t) __builtin_ctz(m);
+		const uint32_t kk = load_key<KEY2>(in, ws + k * SUB + lane * 8, n);
+		const uint32_t inc = wave_incl_scan_dpp(key_extra_bytes<KEY2>(kk));
+		if (lane == 63)
+			s_sub[w][k] = inc;
+	}
+	wave_lds_sync();
+	if (lane < CK) {
+		const uint32_t v = s_sub[w][lane];
+		const uint32_t inc = wave_incl_scan_dpp(v);
+		s_epre[w][lane] = inc - v;
+	}
+	wave_lds_sync();
 
 	// ---- phase 1: data loads of the plain sub-tiles (8 bytes per lane, any alignment)
 	uint2 dat[CK];
-	{
-		uint64_t eb = ebase;
 #pragma unroll
-		for (int k = 0; k < CK; k++) {
-			const uint32_t i0 = ws + k * SUB + lane * 8;
-			const uint32_t sub0 = ws + k * SUB;
-			uint2 dd = make_uint2(0, 0);
-			if (sub0 < n) { // uniform
-				// a sub-tile whose 8-byte windows could reach past the stream is not plain
-				if (!((kmask >> k) & 1u) && eb + sub0 + SUB + 8 > dlen)
-					kmask |= 1u << k;
-				if (!((kmask >> k) & 1u)) {
-					if (i0 < n)
-						__builtin_memcpy(&dd, data + eb + i0, 8);
-				} else {
-					const uint32_t kk = load_key<KEY2>(in, i0, n);
-					const uint32_t inc = wave_incl_scan_dpp(key_extra_bytes<KEY2>(kk));
-					eb += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
-				}
-			}
-			dat[k] = dd;
+	for (int k = 0; k < CK; k++) {
+		const uint32_t i0 = ws + k * SUB + lane * 8;
+		uint2 dd = make_uint2(0, 0);
+		if ((plain >> k) & 1u) { // uniform
+			const uint64_t eb = ebase + uni(s_epre[w][k]);
+			if (i0 < n)
+				__builtin_memcpy(&dd, data + eb + i0, 8);
 		}
+		dat[k] = dd;
 	}
 
-	// ---- phase 2: sum of the deltas in front of every lane's 8 samples (16-bit wraparound)
-	uint32_t lbase[CK / 2]; // two 16-bit bases per register
-	uint32_t wsum = 0;
+	// ---- phase 2: delta sums (16-bit wraparound) - per lane inside its sub-tile, per sub-tile
 	if (ZD) {
-		uint64_t eb = ebase;
 #pragma unroll
 		for (int k = 0; k < CK; k++) {
-			const uint32_t i0 = ws + k * SUB + lane * 8;
-			uint32_t lb = 0;
-			if (ws + k * SUB < n) { // uniform
+			if ((plain >> k) & 1u) { // uniform
 				uint32_t v[4];
-				if (!((kmask >> k) & 1u))
-					expand8(dat[k], v);
-				else
-					eb += gather_slow<KEY2>(in, data, dlen, i0, n, eb, v);
+				expand8(dat[k], v);
 				uint32_t acc = 0;
 #pragma unroll
 				for (int q = 0; q < 4; q++)
 					acc = pk_add16(acc, unzz_pair(v[q]));
 				const uint32_t tot16 = (acc + (acc >> 16)) & 0xFFFFu;
 				const uint32_t inc = wave_incl_scan_dpp(tot16);
-				lb = (wsum + inc - tot16) & 0xFFFFu;
-				wsum += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+				s_xl[w][k][lane] = (uint16_t) (inc - tot16);
+				if (lane == 63)
+					s_sub[w][k] = inc;
 			}
-			if (k & 1)
-				lbase[k >> 1] |= lb << 16;
-			else
-				lbase[k >> 1] = lb;
 		}
+		for (uint32_t m = kmask; m; m &= m - 1) {
+			const uint32_t k = (uint32_t) __builtin_ctz(m);
+			const uint32_t i0 = ws + k * SUB + lane * 8;
+			uint32_t v[4];
+			(void) gather_slow<KEY2>(in, data, dlen, i0, n, ebase + uni(s_epre[w][k]), v);
+			uint32_t acc = 0;
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+				acc = pk_add16(acc, unzz_pair(v[q]));
+			const uint32_t tot16 = (acc + (acc >> 16)) & 0xFFFFu;
+			const uint32_t inc = wave_incl_scan_dpp(tot16);
+			s_xl[w][k][lane] = (uint16_t) (inc - tot16);
+			if (lane == 63)
+				s_sub[w][k] = inc;
+		}
+		wave_lds_sync();
+		// exclusive prefix over the sub-tiles of the wave
+		uint32_t wtot = 0;
+		{
+			const uint32_t v = (lane < (int) nsub) ? s_sub[w][lane < CK ? lane : 0] : 0u;
+			const uint32_t inc = wave_incl_scan_dpp(v);
+			wave_lds_sync();
+			if (lane < CK)
+				s_sub[w][lane] = inc - v;
+			wtot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+		}
+		wave_lds_sync();
+		if (lane == 0)
+			s_wsum[w] = wtot & 0xFFFFu;
 	}
+	STAMP(3);
 
 	// ---- sample value in front of this wave: within the chunk (LDS) and before it (look-back)
 	uint32_t sb = 0;
 	if (ZD) {
-		if (lane == 0)
-			s_wsum[w] = wsum & 0xFFFFu;
 		__syncthreads();
+		STAMP(4);
 		const uint32_t u0 = uni(s_wsum[0]), u1 = uni(s_wsum[1]), u2 = uni(s_wsum[2]), u3 = uni(s_wsum[3]);
 		if (w == 0) {
 			const uint32_t sv = (uint32_t) lookback(a.gran, t, d.j, (uint64_t) ((u0 + u1 + u2 + u3) & 0xFFFFu), last);
@@ -723,41 +803,65 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 		__syncthreads();
 		sb = uni(s_sbase) + (w > 0 ? u0 : 0u) + (w > 1 ? u1 : 0u) + (w > 2 ? u2 : 0u);
 	}
+	STAMP(5);
+
+	// Every load has completed by now (the barrier above drains vmcnt).  Re-define the payload
+	// registers through an empty asm so that the compiler stops associating them with memory
+	// operations: otherwise it puts an s_waitcnt vmcnt(0) in front of every sub-tile of the
+	// store loop and each 16-byte store is drained before the next one is issued.
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+	for (int k = 0; k < CK; k++)
+		asm volatile("" : "+v"(dat[k].x), "+v"(dat[k].y));
 
 	// ---- phase 3: expand again, prefix inside the lane, add the bases, store
-	{
-		uint64_t eb = ebase;
 #pragma unroll
-		for (int k = 0; k < CK; k++) {
-			const uint32_t i0 = ws + k * SUB + lane * 8;
-			if (ws + k * SUB < n) { // uniform
-				uint32_t v[4];
-				if (!((kmask >> k) & 1u))
-					expand8(dat[k], v);
-				else
-					eb += gather_slow<KEY2>(in, data, dlen, i0, n, eb, v);
-				if (ZD) {
+	for (int k = 0; k < CK; k++) {
+		const uint32_t i0 = ws + k * SUB + lane * 8;
+		if ((plain >> k) & 1u) { // uniform; plain sub-tiles hold only complete lanes
+			uint32_t v[4];
+			expand8(dat[k], v);
+			if (ZD) {
 #pragma unroll
-					for (int q = 0; q < 4; q++)
-						v[q] = unzz_pair(v[q]);
-					(void) lane_prefix8(v);
-					const uint32_t b16 = (sb + ((lbase[k >> 1] >> (16 * (k & 1))) & 0xFFFFu)) & 0xFFFFu;
-					const uint32_t b2 = b16 | (b16 << 16);
+				for (int q = 0; q < 4; q++)
+					v[q] = unzz_pair(v[q]);
+				(void) lane_prefix8(v);
+				const uint32_t b16 = (sb + uni(s_sub[w][k]) + s_xl[w][k][lane]) & 0xFFFFu;
+				const uint32_t b2 = b16 | (b16 << 16);
 #pragma unroll
-					for (int q = 0; q < 4; q++)
-						v[q] = pk_add16(v[q], b2);
-				}
-				if (i0 + 8 <= n) {
-					*reinterpret_cast<uint4 *>(out + i0) = make_uint4(v[0], v[1], v[2], v[3]);
-				} else if (i0 < n) {
-#pragma unroll
-					for (uint32_t q = 0; q < 8; q++)
-						if (q < n - i0)
-							out[i0 + q] = (int16_t) (v[q >> 1] >> (16 * (q & 1)));
-				}
+				for (int q = 0; q < 4; q++)
+					v[q] = pk_add16(v[q], b2);
 			}
+			if (i0 < n)
+				*reinterpret_cast<uint4 *>(out + i0) = make_uint4(v[0], v[1], v[2], v[3]);
 		}
 	}
+	for (uint32_t m = kmask; m; m &= m - 1) {
+		const uint32_t k = (uint32_t) __builtin_ctz(m);
+		const uint32_t i0 = ws + k * SUB + lane * 8;
+		uint32_t v[4];
+		(void) gather_slow<KEY2>(in, data, dlen, i0, n, ebase + uni(s_epre[w][k]), v);
+		if (ZD) {
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+				v[q] = unzz_pair(v[q]);
+			(void) lane_prefix8(v);
+			const uint32_t b16 = (sb + uni(s_sub[w][k]) + s_xl[w][k][lane]) & 0xFFFFu;
+			const uint32_t b2 = b16 | (b16 << 16);
+#pragma unroll
+			for (int q = 0; q < 4; q++)
+				v[q] = pk_add16(v[q], b2);
+		}
+		if (i0 + 8 <= n) {
+			*reinterpret_cast<uint4 *>(out + i0) = make_uint4(v[0], v[1], v[2], v[3]);
+		} else if (i0 < n) {
+#pragma unroll
+			for (uint32_t q = 0; q < 8; q++)
+				if (q < n - i0)
+					out[i0 + q] = (int16_t) (v[q >> 1] >> (16 * (q & 1)));
+		}
+	}
+	STAMP(6);
 }
 
 // ------------------------------------------------------------------ launchers
