@@ -544,7 +544,9 @@ __device__ __forceinline__ void expand8(uint2 dd, uint32_t v[4])
 // kernel then starts its data loads straight from the chunk descriptor.
 
 // One workgroup per chunk: per wave quarter, which sub-tiles are not plain and how many
-// extra data bytes (exceptions) the quarter holds.
+// extra data bytes (exceptions) the quarter holds.  A wave quarter's key bytes are contiguous
+// (1 KiB for svb16, 2 KiB for svb32): each lane takes 16 of them with one (unaligned) 16-byte
+// load, the count is one popcount reduction and the per-sub-tile flags come from one ballot.
 template <bool KEY2>
 __global__ __launch_bounds__(CWG) void k_svb_keyscan(DecodeArgs a)
 {
@@ -552,36 +554,77 @@ __global__ __launch_bounds__(CWG) void k_svb_keyscan(DecodeArgs a)
 	if (c >= a.ctl->nchunks)
 		return;
 	ChunkDesc *dp = a.chunks + c;
-	if (!dp->cap_ok)
+	if (!uni(dp->cap_ok))
 		return;
-	const uint32_t n = dp->n;
-	const uint8_t *in = a.in + dp->out_base;
+	const uint32_t n = uni(dp->n);
+	const uint8_t *in = a.in + uni64(dp->out_base);
+	const uint64_t in_len = uni64(a.in_len[uni(dp->read)]);
+	const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
 	const int lane = threadIdx.x & 63;
 	const int w = (int) uni(threadIdx.x >> 6);
-	const uint32_t ws = dp->j * CHUNK + w * WAVE_SAMPLES;
-	uint32_t key[CK];
-#pragma unroll
-	for (int k = 0; k < CK; k++)
-		key[k] = load_key<KEY2>(in, ws + k * SUB + lane * 8, n);
+	const uint32_t ws = uni(dp->j) * CHUNK + w * WAVE_SAMPLES;
+	constexpr int NL = KEY2 ? 2 : 1;            // 16-byte loads per lane
+	constexpr uint32_t SPB = KEY2 ? 4 : 8;      // samples per key byte
+	uint32_t cnt = 0;
 	uint32_t kmask = 0;
-	uint64_t etot = 0;
+	uint32_t bad = 0;
 #pragma unroll
-	for (int k = 0; k < CK; k++) {
-		const uint32_t i0 = ws + k * SUB + lane * 8;
-		const bool ragged = i0 < n && i0 + 8 > n;
-		const unsigned long long bx = __ballot(key[k] != 0);
-		const unsigned long long br = __ballot(ragged);
-		if (bx | br)
-			kmask |= 1u << k;
-		if (bx) {
-			// 3- and 4-byte codes cannot come from a 16-bit signal: poison the count so that
-			// the read fails its length check and its offsets fall out of range
-			if (KEY2 && __ballot((key[k] & 0xAAAAu) != 0))
-				etot += 1u << 30;
-			const uint32_t inc = wave_incl_scan_dpp(key_extra_bytes<KEY2>(key[k]));
-			etot += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+	for (int h = 0; h < NL; h++) {
+		// key bytes [kb, kb+16) of the stream = samples [kb*SPB, (kb+16)*SPB)
+		const uint32_t kb = ws / SPB + h * 1024 + lane * 16;
+		uint32_t q[4] = { 0, 0, 0, 0 };
+		if (kb < klen) {
+			// (the stream's very last key byte may carry bits of samples beyond n: byte path)
+			if ((uint64_t) kb + 16 <= in_len && (kb + 16 < klen || (kb + 16 == klen && n % SPB == 0))) {
+				uint4 v;
+				__builtin_memcpy(&v, in + kb, 16);
+				q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+			} else {
+				for (uint32_t b = 0; b < 16 && kb + b < klen; b++) {
+					uint32_t kk = in[kb + b];
+					// bits of samples at or beyond n do not count
+					const uint32_t s0 = (kb + b) * SPB;
+					if (s0 + SPB > n)
+						kk &= (1u << ((n - s0) * (KEY2 ? 2 : 1))) - 1u;
+					q[b >> 2] |= kk << (8 * (b & 3));
+				}
+			}
+		}
+		uint32_t any = q[0] | q[1] | q[2] | q[3];
+		if (!KEY2) {
+			cnt += __popc(q[0]) + __popc(q[1]) + __popc(q[2]) + __popc(q[3]);
+		} else {
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				// sum of the 2-bit codes: low bits + 2 x high bits
+				cnt += __popc(q[i] & 0x55555555u) + 2 * __popc(q[i] & 0xAAAAAAAAu);
+				bad |= q[i] & 0xAAAAAAAAu;
+			}
+		}
+		// sub-tile k of this wave = key bytes [k*64/NL', ...): svb16: 64 bytes = 4 lanes;
+		// svb32: 128 bytes = 8 lanes of this half... lanes are ordered by key byte
+		const unsigned long long nz = __ballot(any != 0);
+		if (!KEY2) {
+#pragma unroll
+			for (int k = 0; k < CK; k++)
+				if ((nz >> (4 * k)) & 0xFull)
+					kmask |= 1u << k;
+		} else {
+#pragma unroll
+			for (int k = 0; k < CK / 2; k++)
+				if ((nz >> (8 * k)) & 0xFFull)
+					kmask |= 1u << (k + h * (CK / 2));
 		}
 	}
+	// ragged tail: the sub-tile that holds sample n-1 when n is not a multiple of 8
+	if ((n & 7) && n > ws && n - ws <= WAVE_SAMPLES)
+		kmask |= 1u << ((n - 1 - ws) / SUB);
+	const uint32_t inc = wave_incl_scan_dpp(cnt);
+	uint64_t etot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+	// 3- and 4-byte codes cannot come from a 16-bit signal: poison the count so that the
+	// read fails its length check and its offsets fall out of range
+	if (KEY2 && __ballot(bad != 0))
+		etot += 1u << 30;
 	if (lane == 0) {
 		dp->ecnt[w] = (uint32_t) (etot > 0xFFFFFFFFull ? 0xFFFFFFFFull : etot);
 		dp->kmask[w] = (uint16_t) kmask;
