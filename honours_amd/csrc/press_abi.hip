@@ -209,6 +209,52 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 				h.lut[i] = (uint16_t) (s | (l << 8));
 		}
 	}
+	// second-level tables for the long codes, grouped by their first HUF_LUT_BITS bits
+	{
+		int nid = 0;
+		uint32_t used = 0;
+		int id_of[1 << HUF_LUT_BITS];
+		for (int i = 0; i < (1 << HUF_LUT_BITS); i++)
+			id_of[i] = -1;
+		uint32_t depth[256] = { 0 };
+		int prefix_of[256];
+		for (int s = 0; s < 256; s++) {
+			if (len[s] <= (uint32_t) HUF_LUT_BITS)
+				continue;
+			const int pfx = (int) (bits[s] & ((1u << HUF_LUT_BITS) - 1));
+			if (id_of[pfx] < 0 && nid < 256) {
+				prefix_of[nid] = pfx;
+				id_of[pfx] = nid++;
+			}
+			if (id_of[pfx] >= 0 && len[s] - HUF_LUT_BITS > depth[id_of[pfx]])
+				depth[id_of[pfx]] = len[s] - HUF_LUT_BITS;
+		}
+		for (int id = 0; id < nid; id++) {
+			if (used + (1u << depth[id]) > (uint32_t) HUF_L2_ENTRIES)
+				continue; // does not fit: this prefix keeps 0xFFFF and walks the trie
+			h.l2off[id] = (uint16_t) used;
+			h.l2bits[id] = (uint8_t) depth[id];
+			h.lut[prefix_of[id]] = (uint16_t) (0x8000u | (uint32_t) id);
+			used += 1u << depth[id];
+		}
+		for (int s = 0; s < 256; s++) {
+			if (len[s] <= (uint32_t) HUF_LUT_BITS)
+				continue;
+			const int pfx = (int) (bits[s] & ((1u << HUF_LUT_BITS) - 1));
+			const int id = id_of[pfx];
+			if (id < 0 || h.lut[pfx] != (uint16_t) (0x8000u | (uint32_t) id))
+				continue;
+			const uint32_t rest = (uint32_t) (bits[s] >> HUF_LUT_BITS), rl = len[s] - HUF_LUT_BITS;
+			for (uint32_t i = rest; i < (1u << depth[id]); i += 1u << rl)
+				h.lut2[h.l2off[id] + i] = (uint16_t) (s | (len[s] << 8));
+		}
+	}
+	h.minlen = 64;
+	h.maxlen = 0;
+	for (int s = 0; s < 256; s++) {
+		h.minlen = len[s] < h.minlen ? len[s] : h.minlen;
+		h.maxlen = len[s] > h.maxlen ? len[s] : h.maxlen;
+	}
 	if (g.huff.reserve(sizeof(HuffDev)))
 		return PRESS_HIP_EHIP;
 	HIPCHK(hipMemcpy(g.huff.p, &h, sizeof h, hipMemcpyHostToDevice));

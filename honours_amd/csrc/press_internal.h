@@ -30,11 +30,18 @@ struct ReadMeta {
 
 // Static-Huffman tables on the device (built on the host from the 256 {len,bits} pairs).
 constexpr int HUF_LUT_BITS = 12;
+constexpr int HUF_L2_ENTRIES = 4096;
 struct HuffDev {
 	uint32_t enc[256];                 // code bits (bit k = k-th emitted bit) | len << 24
 	uint16_t lut[1 << HUF_LUT_BITS];   // sym | len << 8 for codes <= 12 bits, 0xFFFF: walk the trie
 	int16_t child[1024][2];            // binary trie, node 0 = root, -1 = none
 	int16_t leaf[1024];                // symbol at a leaf, -1 otherwise
+	uint32_t minlen, maxlen;           // shortest / longest code
+	// second level for codes longer than HUF_LUT_BITS: lut[prefix] = 0x8000 | id, then
+	// lut2[l2off[id] + next l2bits[id] stream bits] = sym | len << 8 (0xFFFF: no such code)
+	uint16_t lut2[HUF_L2_ENTRIES];
+	uint16_t l2off[256];
+	uint8_t l2bits[256];
 };
 
 // ---- chunked (v2) svb kernels: a read is cut into chunks of CHUNK samples, one workgroup

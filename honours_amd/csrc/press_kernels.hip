@@ -15,6 +15,8 @@
 //
 // Formats and the reference lines they restate are cited per kernel.
 
+#include <stdlib.h>
+
 #include "press_internal.h"
 
 namespace ph {
@@ -1012,7 +1014,7 @@ __global__ __launch_bounds__(64) void k_huff_decode(DecodeArgs a)
 		}
 		uint32_t e = lut[(uint32_t) acc & ((1u << HUF_LUT_BITS) - 1u)];
 		uint32_t sym, len;
-		if (e != 0xFFFFu) {
+		if (e < 0x8000u) {
 			sym = e & 0xFFu;
 			len = e >> 8;
 		} else {
@@ -1034,6 +1036,258 @@ __global__ __launch_bounds__(64) void k_huff_decode(DecodeArgs a)
 		used += len;
 	}
 	m->nlow = got;
+}
+
+// ------------------------------------------------------------------ decode: static Huffman, parallel
+//
+// The stream has no synchronisation points, but Huffman codes self-synchronise: a decoder
+// started at a wrong bit position falls back onto true code boundaries after a few codes.
+// One workgroup per read walks the bit stream in tiles of HT x S bits.  Thread i owns the
+// codes that START in its S-bit subsequence:
+//   pass 0   thread i decodes from the start of its subsequence (only thread 0's start -
+//            carried from the previous tile - is known to be a code boundary) and records
+//            where the first code of the next subsequence starts, E[i], and its count C[i];
+//   repeat   thread i takes E[i-1] as its start; if that differs from what it used before
+//            it decodes again; until no start changes (thread i is final after <= i
+//            rounds, in practice after 2-3; a code that never re-synchronises only costs
+//            rounds, never correctness);
+//   then     prefix sum of C -> output offsets, decode once more writing the symbols to
+//            LDS, flush with aligned 16-byte stores.
+// Result == huffman.c:1219 bit for bit, including its behaviour at the end of the input
+// (stops when the bytes run out or the symbol count is reached).
+
+constexpr int HT = 512;                 // threads per workgroup
+constexpr int HSYM = 32;                // most symbols a subsequence can hold (S = min(128, 32*minlen))
+constexpr uint32_t HEND = 0xFFFFFFFFu;  // "no further code": end of input or an undecodable prefix
+
+// decode the codes that start in [s, sub_end); returns where the next one starts.
+// lbits: LDS dwords of the tile, lbase = bit position of lbits[0]
+template <bool WRITE>
+__device__ __forceinline__ uint32_t huff_sub(const uint32_t *lbits, uint32_t lbase, const uint16_t *lut,
+					     const uint16_t *lut2, const uint16_t *l2off, const uint8_t *l2bits,
+					     const HuffDev *hd, uint32_t s, uint32_t sub_end, uint32_t nbits,
+					     uint32_t &cnt, uint8_t *dst, uint32_t maxw)
+{
+	uint32_t p = s;
+	cnt = 0;
+	while (p < sub_end) {
+		if (p >= nbits)
+			return HEND;
+		const uint32_t lp = p - lbase;
+		const uint64_t wnd = ((uint64_t) lbits[(lp >> 5) + 1] << 32 | lbits[lp >> 5]) >> (lp & 31);
+		uint32_t e = lut[(uint32_t) wnd & ((1u << HUF_LUT_BITS) - 1u)];
+		uint32_t sym, len;
+		if (e >= 0x8000u && e != 0xFFFFu) { // long code: second-level table
+			const uint32_t id = e & 0xFFu;
+			e = lut2[l2off[id] + ((uint32_t) (wnd >> HUF_LUT_BITS) & ((1u << l2bits[id]) - 1u))];
+			if (e == 0xFFFFu)
+				return HEND; // no such code
+		}
+		if (e != 0xFFFFu) {
+			sym = e & 0xFFu;
+			len = e >> 8;
+		} else {
+			int node = 0;
+			len = 0;
+			while (node >= 0 && hd->leaf[node] < 0 && len < 32) {
+				node = hd->child[node][(uint32_t) (wnd >> len) & 1u];
+				len++;
+			}
+			if (node < 0 || hd->leaf[node] < 0)
+				return HEND; // no such code
+			sym = (uint32_t) hd->leaf[node];
+		}
+		if (p + len > nbits)
+			return HEND; // the code runs off the end of the input
+		if (WRITE && cnt < maxw)
+			dst[cnt] = (uint8_t) sym;
+		cnt++;
+		p += len;
+	}
+	return p;
+}
+
+#ifdef HUF_DEBUG
+__device__ unsigned long long g_hufdbg[8];
+extern "C" int press_hip_debug_huff(unsigned long long *dst)
+{
+	int rc = (int) hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_hufdbg), sizeof g_hufdbg);
+	unsigned long long z[8] = { 0 };
+	(void) hipMemcpyToSymbol(HIP_SYMBOL(g_hufdbg), z, sizeof z);
+	return rc;
+}
+#endif
+
+__global__ __launch_bounds__(HT) void k_huff_decode_par(DecodeArgs a)
+{
+	__shared__ uint16_t lut[1 << HUF_LUT_BITS];
+	__shared__ uint16_t lut2[HUF_L2_ENTRIES];
+	__shared__ uint16_t l2off[256];
+	__shared__ uint8_t l2bits[256];
+	__shared__ __attribute__((aligned(16))) uint32_t lbits[HT * 4 + 8];
+	__shared__ uint32_t sE[HT];
+	__shared__ uint32_t sC[HT];
+	__shared__ uint32_t wtot[HT / 64];
+	__shared__ __attribute__((aligned(16))) uint8_t obuf[16 + HT * HSYM + 16];
+
+	const uint32_t r = blockIdx.x;
+	ReadMeta *m = a.meta + r;
+	if (m->status)
+		return;
+	for (uint32_t i = threadIdx.x; i < (1u << HUF_LUT_BITS); i += HT)
+		lut[i] = a.huff->lut[i];
+	for (uint32_t i = threadIdx.x; i < (uint32_t) HUF_L2_ENTRIES; i += HT)
+		lut2[i] = a.huff->lut2[i];
+	if (threadIdx.x < 256) {
+		l2off[threadIdx.x] = a.huff->l2off[threadIdx.x];
+		l2bits[threadIdx.x] = a.huff->l2bits[threadIdx.x];
+	}
+	const uint32_t hdr = m->hdr + m->seclen + 4;
+	const uint8_t *h = a.in + a.in_off[r] + hdr;
+	const uint64_t nbytes64 = a.in_len[r] - hdr;
+	const uint32_t nbytes = nbytes64 > 0x1FFFFFFFull ? 0x1FFFFFFFu : (uint32_t) nbytes64;
+	const uint32_t nbits = nbytes * 8;
+	const uint32_t want = m->nlow;
+	uint8_t *low = a.low + a.off[r];
+	const uint32_t minlen = a.huff->minlen;
+	const uint32_t S = minlen >= 4 ? 128u : 32u * minlen; // bits per subsequence (>= the longest code, 24)
+	const uint32_t tid = threadIdx.x;
+
+	// output FIFO state (see fifo_flush): obuf[0] <-> global address g (16-byte aligned)
+	uint32_t skip = (uint32_t) ((uintptr_t) low & 15);
+	uint8_t *g = low - skip;
+	uint32_t fill = skip;
+
+	uint32_t pos = 0; // bit position of the next tile = a true code boundary
+	uint32_t got = 0;
+	__syncthreads();
+	while (got < want && pos < nbits) {
+		// ---- stage the tile's bits: lbits[j] = payload bytes [4*(pos/32 + j), +4)
+		const uint32_t base_dw = pos >> 5;
+		const uint32_t lbase = base_dw << 5;
+		const uint32_t ndw = (HT * S) / 32 + 4;
+		for (uint32_t j = tid; j < ndw; j += HT) {
+			const uint64_t b = 4ull * (base_dw + j);
+			uint32_t v = 0;
+			if (b + 4 <= nbytes) {
+				__builtin_memcpy(&v, h + b, 4);
+			} else {
+				for (uint32_t q = 0; q < 4; q++)
+					if (b + q < nbytes)
+						v |= (uint32_t) h[b + q] << (8 * q);
+			}
+			lbits[j] = v;
+		}
+		__syncthreads();
+
+#ifdef HUF_DEBUG
+		if (tid == 0)
+			atomicAdd(&g_hufdbg[0], 1ull); // tiles
+#endif
+		// ---- pass 0 and the synchronisation rounds
+		const uint32_t sub0 = pos + tid * S;
+		const uint32_t sub_end = sub0 + S;
+		uint32_t start = sub0;
+		uint32_t cnt;
+		uint32_t e = huff_sub<false>(lbits, lbase, lut, lut2, l2off, l2bits, a.huff, start, sub_end, nbits, cnt, nullptr, 0);
+		sE[tid] = e;
+		sC[tid] = cnt;
+		for (;;) {
+			__syncthreads();
+			int changed = 0;
+			const uint32_t ns = tid ? sE[tid - 1] : pos;
+			if (ns != start) {
+				start = ns;
+				changed = 1;
+			}
+			if (__syncthreads_or(changed) == 0)
+				break;
+#ifdef HUF_DEBUG
+			if (tid == 0)
+				atomicAdd(&g_hufdbg[1], 1ull); // rounds
+			if (changed)
+				atomicAdd(&g_hufdbg[2], 1ull); // re-decodes
+#endif
+			if (changed) {
+				if (start == HEND) {
+					e = HEND;
+					cnt = 0;
+				} else {
+					e = huff_sub<false>(lbits, lbase, lut, lut2, l2off, l2bits, a.huff, start, sub_end, nbits, cnt, nullptr, 0);
+				}
+				sE[tid] = e;
+				sC[tid] = cnt;
+			}
+		}
+
+		// ---- offsets: exclusive prefix of the counts over the workgroup
+		uint32_t inc = cnt;
+		{
+			const int lane = tid & 63;
+#pragma unroll
+			for (int dd = 1; dd < 64; dd <<= 1) {
+				const uint32_t t2 = __shfl_up(inc, dd, 64);
+				if (lane >= dd)
+					inc += t2;
+			}
+			if (lane == 63)
+				wtot[tid >> 6] = inc;
+		}
+		__syncthreads();
+		uint32_t base = 0, total = 0;
+#pragma unroll
+		for (int w2 = 0; w2 < HT / 64; w2++) {
+			const uint32_t x = wtot[w2];
+			if (w2 < (int) (tid >> 6))
+				base += x;
+			total += x;
+		}
+		const uint32_t excl = base + inc - cnt;
+		const uint32_t room = want - got;                 // symbols still wanted
+		const uint32_t take = total < room ? total : room; // symbols this tile delivers
+		const uint32_t maxw = excl < take ? take - excl : 0u;
+		// ---- final pass: symbols into the LDS FIFO
+		if (cnt && maxw && start != HEND) {
+			uint32_t c2;
+			(void) huff_sub<true>(lbits, lbase, lut, lut2, l2off, l2bits, a.huff, start, sub_end, nbits, c2, obuf + fill + excl, maxw);
+		}
+		const uint32_t last_e = sE[HT - 1];
+		__syncthreads();
+		// flush whole 16-byte chunks, keep the rest for the next tile
+		{
+			const uint32_t tot = fill + take;
+			const uint32_t nch = tot >> 4;
+			for (uint32_t c = tid; c < nch; c += HT) {
+				const uint4 v = reinterpret_cast<const uint4 *>(obuf)[c];
+				if (c == 0 && skip) {
+					const uint32_t wv[4] = { v.x, v.y, v.z, v.w };
+					for (uint32_t b = skip; b < 16; b++)
+						g[b] = (uint8_t) (wv[b >> 2] >> (8 * (b & 3)));
+				} else {
+					reinterpret_cast<uint4 *>(g)[c] = v;
+				}
+			}
+			if (nch) {
+				if (tid == 0) {
+					const uint4 tl = reinterpret_cast<const uint4 *>(obuf)[nch];
+					reinterpret_cast<uint4 *>(obuf)[0] = tl;
+				}
+				skip = 0;
+			}
+			g += (size_t) nch * 16;
+			fill = tot & 15;
+		}
+		got += take;
+		if (last_e == HEND || take < total)
+			break;
+		pos = last_e;
+		__syncthreads();
+	}
+	__syncthreads();
+	for (uint32_t b = skip + tid; b < fill; b += HT)
+		g[b] = obuf[b];
+	if (tid == 0)
+		m->nlow = got;
 }
 
 // ------------------------------------------------------------------ decode: merge + undo zig-zag delta
@@ -1184,12 +1438,16 @@ void launch_ex_encode(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
 
 void launch_ex_decode(const DecodeArgs &a, int fmt, bool huff, hipStream_t s)
 {
+	const bool huff_parallel = getenv("PRESS_HIP_HUFF_SERIAL") == nullptr;
 	if (!a.nreads)
 		return;
 	const dim3 grid(a.nreads);
 	hipLaunchKernelGGL(k_ex_parse, grid, dim3(64), 0, s, a, fmt, huff ? 1 : 0);
 	if (huff) {
-		hipLaunchKernelGGL(k_huff_decode, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a);
+		if (huff_parallel)
+			hipLaunchKernelGGL(k_huff_decode_par, grid, dim3(HT), 0, s, a);
+		else // codes longer than a subsequence could hold: one lane per read
+			hipLaunchKernelGGL(k_huff_decode, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a);
 		hipLaunchKernelGGL((k_low_decode<true>), grid, dim3(WG), 0, s, a);
 	} else {
 		hipLaunchKernelGGL((k_low_decode<false>), grid, dim3(WG), 0, s, a);
