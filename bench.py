@@ -119,6 +119,7 @@ def main():
     comp_bytes = int(lens.sum())
 
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    press.kernel_timing(True)  # HIP events around the dominant kernel of each call, on its launch stream
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -131,6 +132,11 @@ def main():
     elapsed = t1 - t0
     press_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
     depress_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+    kpress = press.kernel_times(0)
+    kdepress = press.kernel_times(1)
+    press.kernel_timing(False)
+    kpress_ms = float(np.mean(kpress)) if kpress else press_ms
+    kdepress_ms = float(np.mean(kdepress)) if kdepress else depress_ms
     # the only collective: 24 bytes of totals (+ the slowest rank's time) over RCCL
     raw_all, comp_all, reads_all, elapsed = shard.reduce_totals(raw_bytes, comp_bytes, R, elapsed, dev)
 
@@ -138,11 +144,27 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = raw_all / (elapsed / args.steps) / 1e6
         ratio = raw_all / comp_all
-        # roofline of the dominant kernel(s): algorithmic bytes = 2n read + c written (press),
-        # c read + 2n written (depress) - DESIGN.md "Measurement"
+        # Roofline: algorithmic bytes per launch = sum over the batch of
+        # 2n (int16 samples) + c (compressed stream), read + written once; the dominant kernel is
+        # the longer of the two main kernels, timed with HIP events on its own launch stream.
         alg = raw_bytes + comp_bytes
-        press_gbps = alg / (press_ms * 1e-3) / 1e9
-        depress_gbps = alg / (depress_ms * 1e-3) / 1e9
+        kern = {"svb12_zd": ("k_svb_encode_chunked<false,true>", "k_svb_decode_chunked<false,true>"),
+                "svb_zd": ("k_svb_encode_chunked<true,true>", "k_svb_decode_chunked<true,true>"),
+                "shuffman_vbe21_zd": ("k_low_encode<true>", "k_huff_decode_par")}.get(
+                    m, ("k_low_encode<false>", "k_low_decode<false>"))
+        traffic = measured_traffic(m, R, args.seed, args.fixed_len)
+
+        def roof(name, ms, call_ms, key):
+            gbps = alg / (ms * 1e-3) / 1e9
+            return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                    "traffic": traffic.get(key) if traffic else None,
+                    "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(ms, 4),
+                    "whole_call_ms": round(call_ms, 4)}
+
+        r_press = roof(kern[0], kpress_ms, press_ms, "press")
+        r_depress = roof(kern[1], kdepress_ms, depress_ms, "depress")
+        dominant, other = (r_depress, r_press) if kdepress_ms >= kpress_ms else (r_press, r_depress)
         out = {
             "metric": "raw-signal MB/s (compress+decompress)",
             "value": round(value, 1),
@@ -168,28 +190,8 @@ def main():
             "ratio_vs_vbz": round(ratio / VBZ_RATIO, 6),
             "press_MBps": round(raw_bytes / (press_ms * 1e-3) / 1e6, 1),
             "depress_MBps": round(raw_bytes / (depress_ms * 1e-3) / 1e6, 1),
-            "roofline": {
-                "kernel": "press (all kernels of press_batch)",
-                "bound": "hbm",
-                "achieved": round(press_gbps, 1),
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": round(press_gbps / HBM_PEAK_GBPS, 4),
-                "traffic": None,
-                "algorithmic_bytes_per_launch": alg,
-                "avg_launch_ms": round(press_ms, 4),
-            },
-            "roofline_depress": {
-                "kernel": "depress (all kernels of depress_batch)",
-                "bound": "hbm",
-                "achieved": round(depress_gbps, 1),
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": round(depress_gbps / HBM_PEAK_GBPS, 4),
-                "traffic": None,
-                "algorithmic_bytes_per_launch": alg,
-                "avg_launch_ms": round(depress_ms, 4),
-            },
+            "roofline": dominant,
+            "roofline_other": other,
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(m, sig, starts, n)
@@ -197,6 +199,24 @@ def main():
 
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(m, reads, seed, fixed_len):
+    """HBM bytes per launch of the main kernels from the committed PMC passes
+    (profiles/*traffic*.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+    gfx950 corrections of MI355X_MICROARCH.md applied) - only for the exact workload they were
+    collected on; None otherwise."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        w = t.get("workload", {})
+        if (w.get("method"), w.get("reads_per_gpu"), w.get("seed"), w.get("fixed_len")) == (m, reads, seed, fixed_len):
+            return t.get("traffic_bytes_per_launch")
+    return None
 
 
 def cpu_baseline(m, sig, starts, n):

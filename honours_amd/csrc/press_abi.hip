@@ -301,6 +301,63 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 
 } // namespace
 
+// ------------------------------------------------------------------ dominant-kernel timing
+
+namespace {
+constexpr int KT_RING = 128;
+struct KTime {
+	bool on = false;
+	hipEvent_t ev[2][KT_RING][2];
+	bool made = false;
+	int n[2] = { 0, 0 };
+} kt;
+} // namespace
+
+namespace ph {
+void ktime_begin(int which, hipStream_t s)
+{
+	if (kt.on && kt.n[which] < KT_RING)
+		(void) hipEventRecord(kt.ev[which][kt.n[which]][0], s);
+}
+void ktime_end(int which, hipStream_t s)
+{
+	if (kt.on && kt.n[which] < KT_RING) {
+		(void) hipEventRecord(kt.ev[which][kt.n[which]][1], s);
+		kt.n[which]++;
+	}
+}
+} // namespace ph
+
+extern "C" int press_hip_kernel_timing(int enable)
+{
+	int rc = ctx_init();
+	if (rc)
+		return rc;
+	if (enable && !kt.made) {
+		for (int w = 0; w < 2; w++)
+			for (int i = 0; i < KT_RING; i++)
+				for (int e = 0; e < 2; e++)
+					HIPCHK(hipEventCreate(&kt.ev[w][i][e]));
+		kt.made = true;
+	}
+	kt.on = enable != 0;
+	kt.n[0] = kt.n[1] = 0;
+	return 0;
+}
+
+extern "C" int press_hip_kernel_times(int which, float *ms, int max)
+{
+	if (which < 0 || which > 1 || !kt.made)
+		return 0;
+	int n = kt.n[which] < max ? kt.n[which] : max;
+	for (int i = 0; i < n; i++) {
+		if (hipEventSynchronize(kt.ev[which][i][1]) != hipSuccess ||
+		    hipEventElapsedTime(&ms[i], kt.ev[which][i][0], kt.ev[which][i][1]) != hipSuccess)
+			return i;
+	}
+	return n;
+}
+
 // ------------------------------------------------------------------ library control
 
 extern "C" int press_hip_set_device(int device)

@@ -921,7 +921,9 @@ static void run_encode(const BatchArgs &a, hipStream_t s)
 #define EXP_GRID 2048u
 #endif
 	const uint32_t grid = a.max_chunks < EXP_GRID ? a.max_chunks : EXP_GRID;
+	ktime_begin(0, s);
 	hipLaunchKernelGGL((k_svb_encode_chunked<KEY2, ZD>), dim3(grid), dim3(CWG), 0, s, a);
+	ktime_end(0, s);
 }
 
 void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s)
@@ -946,7 +948,9 @@ static void run_decode(const DecodeArgs &a, hipStream_t s)
 	// surplus workgroups (max_chunks bounds the real count from above) exit at once
 	hipLaunchKernelGGL((k_svb_keyscan<KEY2>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	hipLaunchKernelGGL((k_svb_keyprefix<KEY2>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a);
+	ktime_begin(1, s);
 	hipLaunchKernelGGL((k_svb_decode_chunked<KEY2, ZD>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
+	ktime_end(1, s);
 }
 
 void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s)

@@ -111,6 +111,11 @@ struct DecodeArgs {
 	uint32_t max_chunks;
 };
 
+// Optional timing of the dominant kernel of a batch call with HIP events recorded on the
+// launch stream (bench.py's roofline figure): launchers call these around that kernel.
+void ktime_begin(int which, hipStream_t s); // which: 0 = press, 1 = depress
+void ktime_end(int which, hipStream_t s);
+
 // launchers (press_kernels.hip).  All asynchronous on `s`.
 void launch_svb_encode(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s);      // v1: one workgroup per read
 void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s); // v2: chunks + look-back

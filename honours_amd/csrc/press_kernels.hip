@@ -1400,12 +1400,14 @@ void launch_svb_encode(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s)
 	if (!a.nreads)
 		return;
 	const dim3 grid(a.nreads), block(WG);
+	ktime_begin(0, s);
 	if (key2bit)
 		hipLaunchKernelGGL((k_svb_encode<true, true>), grid, block, 0, s, a);
 	else if (zd)
 		hipLaunchKernelGGL((k_svb_encode<false, true>), grid, block, 0, s, a);
 	else
 		hipLaunchKernelGGL((k_svb_encode<false, false>), grid, block, 0, s, a);
+	ktime_end(0, s);
 }
 
 void launch_svb_decode(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s)
@@ -1413,12 +1415,14 @@ void launch_svb_decode(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s
 	if (!a.nreads)
 		return;
 	const dim3 grid(a.nreads), block(WG);
+	ktime_begin(1, s);
 	if (key2bit)
 		hipLaunchKernelGGL((k_svb_decode<true, true>), grid, block, 0, s, a);
 	else if (zd)
 		hipLaunchKernelGGL((k_svb_decode<false, true>), grid, block, 0, s, a);
 	else
 		hipLaunchKernelGGL((k_svb_decode<false, false>), grid, block, 0, s, a);
+	ktime_end(1, s);
 }
 
 void launch_ex_encode(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
@@ -1430,10 +1434,12 @@ void launch_ex_encode(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
 	if (fmt == EXF_EXZD)
 		hipLaunchKernelGGL((k_ex_scan<true>), grid, dim3(WG), 0, s, a);
 	hipLaunchKernelGGL(k_ex_section, grid, dim3(64), 0, s, a, fmt, huff ? 1 : 0);
+	ktime_begin(0, s);
 	if (huff)
 		hipLaunchKernelGGL((k_low_encode<true>), grid, dim3(WG), 0, s, a);
 	else
 		hipLaunchKernelGGL((k_low_encode<false>), grid, dim3(WG), 0, s, a);
+	ktime_end(0, s);
 }
 
 void launch_ex_decode(const DecodeArgs &a, int fmt, bool huff, hipStream_t s)
@@ -1444,13 +1450,17 @@ void launch_ex_decode(const DecodeArgs &a, int fmt, bool huff, hipStream_t s)
 	const dim3 grid(a.nreads);
 	hipLaunchKernelGGL(k_ex_parse, grid, dim3(64), 0, s, a, fmt, huff ? 1 : 0);
 	if (huff) {
+		ktime_begin(1, s);
 		if (huff_parallel)
 			hipLaunchKernelGGL(k_huff_decode_par, grid, dim3(HT), 0, s, a);
 		else // codes longer than a subsequence could hold: one lane per read
 			hipLaunchKernelGGL(k_huff_decode, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a);
+		ktime_end(1, s);
 		hipLaunchKernelGGL((k_low_decode<true>), grid, dim3(WG), 0, s, a);
 	} else {
+		ktime_begin(1, s);
 		hipLaunchKernelGGL((k_low_decode<false>), grid, dim3(WG), 0, s, a);
+		ktime_end(1, s);
 	}
 }
 

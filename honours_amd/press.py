@@ -65,6 +65,7 @@ HEADER_SYMBOLS = sorted(set(
      "press_hip_get_stream",
      "press_hip_synchronize", "press_hip_load_table_file", "press_hip_set_table", "press_hip_bound",
      "press_hip_press_batch", "press_hip_depress_batch", "press_hip_workspace_bytes",
+     "press_hip_kernel_timing", "press_hip_kernel_times",
      "press_hip_shutdown"]))
 
 
@@ -342,3 +343,19 @@ def depress_batch_host(method, streams, ns):
         raise PressError(last_error())
     return [None if int(k) == 0xFFFFFFFF else sig[int(o): int(o) + int(k)].copy()
             for o, k in zip(off, out_n)]
+
+
+def kernel_timing(enable=True):
+    """(re)start / stop the HIP-event timing of the dominant kernel of each batch call"""
+    lib = load_library()
+    if lib.press_hip_kernel_timing(1 if enable else 0):
+        raise PressError(last_error())
+
+
+def kernel_times(which):
+    """elapsed ms of the dominant kernel of every press (which=0) / depress (1) call so far"""
+    lib = load_library()
+    buf = (ctypes.c_float * 128)()
+    lib.press_hip_kernel_times.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    n = lib.press_hip_kernel_times(which, buf, 128)
+    return [buf[i] for i in range(n)]

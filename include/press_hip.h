@@ -222,6 +222,13 @@ int press_hip_depress_batch(int method, const uint8_t *in, const uint64_t *in_of
 /* bytes of device scratch the two calls above keep for a batch of this shape (informational) */
 uint64_t press_hip_workspace_bytes(int method, uint64_t total_samples, uint32_t nreads);
 
+/* Measurement aid (bench.py): when enabled, every batch call brackets its dominant kernel
+ * (the svb encode / decode kernel, the one-byte-stream kernels of the exception methods)
+ * with HIP events on the launch stream.  press_hip_kernel_times(which, ms, max) returns the
+ * elapsed times recorded since timing was (re-)enabled; which: 0 = press, 1 = depress. */
+int press_hip_kernel_timing(int enable);
+int press_hip_kernel_times(int which, float *ms, int max);
+
 /* release every device and host resource held by the library */
 void press_hip_shutdown(void);
 
