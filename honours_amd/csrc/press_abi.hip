@@ -284,7 +284,7 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 {
 	if (g.meta.reserve(((size_t) nreads + 1) * sizeof(ReadMeta)))
 		return PRESS_HIP_EHIP;
-	if (is_svb(method)) {
+	if (is_svb(method) || is_ex(method)) {
 		const size_t mc = max_chunks_of(total_samples, nreads);
 		if (g.chunks.reserve(mc * sizeof(ChunkDesc)) || g.gran.reserve(2 * mc * sizeof(uint64_t)) ||
 		    g.ctl.reserve(sizeof(ChunkCtl)) || g.first_chunk.reserve(((size_t) nreads + 1) * 4))
@@ -481,7 +481,8 @@ static int launch_press(int method, const BatchArgs &a, hipStream_t s)
 	case PRESS_HIP_SVB12_ZD: v1 ? launch_svb_encode(a, false, true, s) : launch_svb_encode_chunked(a, false, true, s); break;
 	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_encode(a, true, true, s) : launch_svb_encode_chunked(a, true, true, s); break;
 	default:
-		launch_ex_encode(a, exfmt_of(method), is_shuff(method), s);
+		v1 ? launch_ex_encode(a, exfmt_of(method), is_shuff(method), s)
+		   : launch_ex_encode_chunked(a, exfmt_of(method), is_shuff(method), s);
 	}
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess)

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 						    const uint64_t *slot_off, const uint64_t *in_len,
 						    uint32_t nreads, ChunkDesc *chunks, uint64_t *gran,
 						    ChunkCtl *ctl, uint32_t max_chunks, uint64_t *out_len,
-						    uint32_t *out_n, uint32_t *first_chunk)
+						    uint32_t *out_n, uint32_t *first_chunk, ReadMeta *meta = nullptr)
 {
 	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
 	uint32_t n = 0, nch = 0;
@@ -188,6 +188,12 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 	const uint32_t first = base + inc - nch;
 	if (r >= nreads)
 		return;
+	if (meta) {
+		ReadMeta z;
+		z.nex = z.ored = z.zd0 = z.q = z.hdr = z.seclen = z.nlow = 0;
+		z.status = 0;
+		meta[r] = z;
+	}
 	const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
 	const uint64_t sbase = slot_off[r];
 	uint32_t ok;
@@ -907,6 +913,272 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 	STAMP(6);
 }
 
+// ------------------------------------------------------------------ exception split, chunked
+//
+// vb1e2 family / ex-zd (press.c:2679-3580, ex_zd.c:9-172): the stream is
+//   header || u32 nex || exception section || one-byte values of the non-exceptions.
+// The section's size depends on ALL exceptions of the read, so the input is read twice:
+//   k_ex_scan_chunked  (ticket order + look-back on the exception count): exception list
+//                      (position, value) at its final rank, per-chunk counts, OR of the samples
+//   k_ex_section       (press_kernels.hip): header + section, one lane per read
+//   k_low_encode_chunked: the one-byte stream; every chunk knows its offset from the counts,
+//                      so no ordering is needed: one workgroup per chunk, 8-byte stores for
+//                      sub-tiles without exceptions exactly as in k_svb_encode_chunked.
+
+// zig-zag deltas of one wave quarter, as in k_svb_encode_chunked phase 1, with the ex-zd
+// shift q applied to the samples first (ex_zd.c:383).  hi[k] != 0 marks lanes with an
+// exception in sub-tile k; sample 0 of the read is never one (it is stored raw).
+__device__ __forceinline__ void quarter_zd(const int16_t *in, uint32_t n, uint32_t ws, int lane, int q,
+					   uint4 (&z)[CK], uint32_t &ored)
+{
+#pragma unroll
+	for (int k = 0; k < CK; k++) {
+		const uint32_t i0 = ws + k * SUB + lane * 8;
+		z[k] = make_uint4(0, 0, 0, 0);
+		if (i0 < n)
+			z[k] = *reinterpret_cast<const uint4 *>(in + i0);
+	}
+	uint32_t carry = 0;
+	if (ws > 0 && ws < n)
+		carry = (uint32_t) (uint16_t) in[ws - 1] << 16;
+	uint32_t o = 0;
+	const s16x2 qq = { (short) q, (short) q };
+#pragma unroll
+	for (int k = 0; k < CK; k++) {
+		const uint32_t i0 = ws + k * SUB + lane * 8;
+		uint32_t r[4] = { z[k].x, z[k].y, z[k].z, z[k].w };
+		// samples at or beyond n: zero (they neither count nor contribute to the OR)
+		if (i0 + 8 > n) {
+			const uint32_t nv = i0 < n ? n - i0 : 0;
+#pragma unroll
+			for (int h = 0; h < 4; h++) {
+				if (nv <= (uint32_t) (2 * h))
+					r[h] = 0;
+				else if (nv == (uint32_t) (2 * h + 1))
+					r[h] &= 0xFFFFu;
+			}
+		}
+		o |= r[0] | r[1] | r[2] | r[3];
+		const uint32_t raw_w = r[3];
+		if (q) {
+#pragma unroll
+			for (int h = 0; h < 4; h++)
+				r[h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, r[h]) >> qq);
+		}
+		uint32_t c = carry;
+		if (q)
+			c = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, c) >> qq);
+		const uint32_t pw = prev_lane(r[3], c);
+		uint32_t zz[4];
+		zz[0] = zd_pair(r[0], pw);
+		zz[1] = zd_pair(r[1], r[0]);
+		zz[2] = zd_pair(r[2], r[1]);
+		zz[3] = zd_pair(r[3], r[2]);
+		carry = (uint32_t) __builtin_amdgcn_readlane((int) raw_w, 63);
+		if (i0 + 8 > n) { // deltas of samples beyond n are garbage: zero them again
+			const uint32_t nv = i0 < n ? n - i0 : 0;
+#pragma unroll
+			for (int h = 0; h < 4; h++) {
+				if (nv <= (uint32_t) (2 * h))
+					zz[h] = 0;
+				else if (nv == (uint32_t) (2 * h + 1))
+					zz[h] &= 0xFFFFu;
+			}
+		}
+		z[k] = make_uint4(zz[0], zz[1], zz[2], zz[3]);
+	}
+	ored = (o | (o >> 16)) & 0xFFFFu;
+}
+
+// 8-bit mask of the samples of a lane that are exceptions (value > 255)
+__device__ __forceinline__ uint32_t exc_mask(const uint4 &z, uint32_t i0)
+{
+	const uint32_t zz[4] = { z.x, z.y, z.z, z.w };
+	uint32_t m = 0;
+#pragma unroll
+	for (int h = 0; h < 4; h++) {
+		m |= ((zz[h] & 0x0000FF00u) ? 1u : 0u) << (2 * h);
+		m |= ((zz[h] & 0xFF000000u) ? 1u : 0u) << (2 * h + 1);
+	}
+	if (i0 == 0)
+		m &= ~1u; // zd[0] is stored raw in the header
+	return m;
+}
+
+template <bool REDO>
+__global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
+{
+	__shared__ uint32_t s_ticket;
+	__shared__ uint32_t s_wtot[4];
+	__shared__ uint64_t s_excl;
+
+	const uint32_t nchunks = uni(a.ctl->nchunks);
+	const int lane = threadIdx.x & 63;
+	const int w = (int) uni(threadIdx.x >> 6);
+	for (;;) {
+		if (threadIdx.x == 0)
+			s_ticket = atomicAdd(&a.ctl->ticket, 1u);
+		__syncthreads();
+		const uint32_t t = uni(s_ticket);
+		if (t >= nchunks)
+			break;
+		ChunkDesc *dp = a.chunks + t;
+		const ChunkU d = load_chunk(dp);
+		const uint32_t n = d.n;
+		const uint32_t first = d.j * CHUNK;
+		const bool last = first + CHUNK >= n;
+		ReadMeta *m = a.meta + d.read;
+		int q = 0;
+		if (REDO) {
+			const uint32_t ored = uni(m->ored);
+			// ex_zd.c:358-381: largest q <= 5 with every sample divisible by 2^q
+			while (q < 5 && !((ored >> q) & 1u))
+				q++;
+			if (q == 0) { // nothing to redo for this read (same decision in all its chunks)
+				__syncthreads();
+				continue;
+			}
+		}
+		const int16_t *in = a.sig + d.sig_off;
+		uint32_t *lpos = a.ex_pos + d.sig_off;
+		uint32_t *lval = a.ex_val + d.sig_off;
+		const uint32_t ws = first + w * WAVE_SAMPLES;
+
+		uint4 z[CK];
+		uint32_t ored;
+		quarter_zd(in, n, ws, lane, q, z, ored);
+		uint32_t kmask = 0, etot = 0;
+#pragma unroll
+		for (int k = 0; k < CK; k++) {
+			const uint32_t i0 = ws + k * SUB + lane * 8;
+			uint32_t hi = (z[k].x | z[k].y | z[k].z | z[k].w) & 0xFF00FF00u;
+			if (i0 == 0)
+				hi = ((z[k].x & 0xFF000000u) | ((z[k].y | z[k].z | z[k].w) & 0xFF00FF00u));
+			if (__ballot(hi != 0)) {
+				kmask |= 1u << k;
+				const uint32_t inc = wave_incl_scan_dpp(__popc(exc_mask(z[k], i0)));
+				etot += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+			}
+		}
+		if (!REDO) { // OR of the raw samples (qts), one atomic per wave
+			uint32_t o = ored;
+#pragma unroll
+			for (int dd = 32; dd >= 1; dd >>= 1)
+				o |= (uint32_t) __shfl_xor((int) o, dd, 64);
+			if (lane == 0 && ws < n)
+				atomicOr(&m->ored, o);
+		}
+		if (lane == 0)
+			s_wtot[w] = etot;
+		__syncthreads();
+		const uint32_t t0 = uni(s_wtot[0]), t1 = uni(s_wtot[1]), t2 = uni(s_wtot[2]), t3 = uni(s_wtot[3]);
+		if (w == 0) {
+			const uint64_t e = lookback(a.gran, t, d.j, (uint64_t) t0 + t1 + t2 + t3, last);
+			if (lane == 0) {
+				s_excl = e;
+				dp->ebefore = e;
+				dp->ecnt[0] = t0;
+				dp->ecnt[1] = t1;
+				dp->ecnt[2] = t2;
+				dp->ecnt[3] = t3;
+				if (last) {
+					m->nex = (uint32_t) e + t0 + t1 + t2 + t3;
+					m->q = (uint32_t) q;
+				}
+			}
+		}
+		__syncthreads();
+		uint32_t rank = (uint32_t) uni64(s_excl) + (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
+		if (first == 0 && threadIdx.x == 0)
+			m->zd0 = z[0].x & 0xFFFFu;
+		// ---- exception list at its final rank
+#pragma unroll
+		for (int k = 0; k < CK; k++) {
+			if (!((kmask >> k) & 1u))
+				continue;
+			const uint32_t i0 = ws + k * SUB + lane * 8;
+			const uint32_t em = exc_mask(z[k], i0);
+			const uint32_t c = __popc(em);
+			const uint32_t inc = wave_incl_scan_dpp(c);
+			uint32_t p = rank + inc - c;
+			const uint32_t zz[4] = { z[k].x, z[k].y, z[k].z, z[k].w };
+			if (em) {
+#pragma unroll
+				for (int h = 0; h < 8; h++) {
+					if ((em >> h) & 1u) {
+						lpos[p] = i0 + h - 1;
+						lval[p] = (zz[h >> 1] >> (16 * (h & 1))) & 0xFFFFu;
+						p++;
+					}
+				}
+			}
+			rank += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+		}
+		__syncthreads(); // every wave has read s_ticket / s_excl before they are overwritten
+	}
+}
+
+// Pass B, plain one-byte stream (press.c:2717-2725): one workgroup per chunk, any order.
+__global__ __launch_bounds__(CWG) void k_low_encode_chunked(BatchArgs a)
+{
+	const uint32_t t = blockIdx.x;
+	if (t >= a.ctl->nchunks)
+		return;
+	const ChunkDesc *dp = a.chunks + t;
+	const ChunkU d = load_chunk(dp);
+	const ReadMeta *m = a.meta + d.read;
+	if (uni(m->status))
+		return; // out_len = FAILED was written by k_ex_section
+	const uint32_t n = d.n;
+	const int lane = threadIdx.x & 63;
+	const int w = (int) uni(threadIdx.x >> 6);
+	const uint32_t ws = d.j * CHUNK + w * WAVE_SAMPLES;
+	if (ws >= n)
+		return;
+	const int q = (int) uni(m->q);
+	const int16_t *in = a.sig + d.sig_off;
+	// one-byte value of sample i (i >= 1) goes to stream[(i - 1) - #exceptions before i]
+	uint8_t *stream = a.out + d.out_base + uni(m->hdr) + uni(m->seclen);
+	const uint32_t e0 = uni(dp->ecnt[0]), e1 = uni(dp->ecnt[1]), e2 = uni(dp->ecnt[2]);
+	uint64_t eb = uni64(dp->ebefore) + (w > 0 ? e0 : 0u) + (w > 1 ? e1 : 0u) + (w > 2 ? e2 : 0u);
+
+	uint4 z[CK];
+	uint32_t ored;
+	quarter_zd(in, n, ws, lane, q, z, ored);
+#pragma unroll
+	for (int k = 0; k < CK; k++) {
+		const uint32_t i0 = ws + k * SUB + lane * 8;
+		const uint32_t sub0 = ws + k * SUB;
+		if (sub0 >= n)
+			continue;
+		uint32_t hi = (z[k].x | z[k].y | z[k].z | z[k].w) & 0xFF00FF00u;
+		const bool special = (i0 == 0) || (i0 < n && i0 + 8 > n); // sample 0 / ragged tail
+		if (!__ballot(hi != 0 || special)) {
+			// no exception in the sub-tile: 8 low bytes per lane, one (unaligned) store
+			if (i0 < n) {
+				uint2 v;
+				v.x = __builtin_amdgcn_perm(z[k].y, z[k].x, 0x06040200);
+				v.y = __builtin_amdgcn_perm(z[k].w, z[k].z, 0x06040200);
+				__builtin_memcpy(stream + (i0 - 1 - eb), &v, 8);
+			}
+			continue;
+		}
+		const uint32_t em = exc_mask(z[k], i0);
+		const uint32_t c = __popc(em);
+		const uint32_t inc = wave_incl_scan_dpp(c);
+		const uint32_t nv = i0 < n ? min(8u, n - i0) : 0u;
+		const uint32_t zz[4] = { z[k].x, z[k].y, z[k].z, z[k].w };
+		// first stream index of this lane: samples before i0 minus sample 0 minus exceptions
+		uint64_t p = (uint64_t) (i0 ? i0 - 1 : 0) - (eb + inc - c);
+#pragma unroll
+		for (int h = 0; h < 8; h++) {
+			if ((uint32_t) h < nv && !((em >> h) & 1u) && !(i0 == 0 && h == 0))
+				stream[p++] = (uint8_t) (zz[h >> 1] >> (16 * (h & 1)));
+		}
+		eb += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+	}
+}
+
 // ------------------------------------------------------------------ launchers
 
 template <bool KEY2, bool ZD>
@@ -951,6 +1223,33 @@ static void run_decode(const DecodeArgs &a, hipStream_t s)
 	ktime_begin(1, s);
 	hipLaunchKernelGGL((k_svb_decode_chunked<KEY2, ZD>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	ktime_end(1, s);
+}
+
+// exception-split encode with the chunked scan; pass B chunked for the plain stream, the v1
+// per-read kernel for the Huffman stream
+void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
+{
+	if (!a.nreads || !a.max_chunks)
+		return;
+	const uint32_t grid = a.max_chunks < EXP_GRID ? a.max_chunks : EXP_GRID;
+	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
+	hipLaunchKernelGGL((k_chunk_prep<false, false>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
+			   a.nsamp, a.out_off, (const uint64_t *) nullptr, a.nreads, a.chunks, a.gran, a.ctl,
+			   a.max_chunks, a.out_len, (uint32_t *) nullptr, (uint32_t *) nullptr, a.meta);
+	hipLaunchKernelGGL((k_ex_scan_chunked<false>), dim3(grid), dim3(CWG), 0, s, a);
+	if (fmt == EXF_EXZD) {
+		// second scan on the shifted samples for reads with q > 0 (fresh tickets and granules)
+		(void) hipMemsetAsync(&a.ctl->ticket, 0, sizeof(uint32_t), s);
+		(void) hipMemsetAsync(a.gran, 0, (size_t) a.max_chunks * sizeof(uint64_t), s);
+		hipLaunchKernelGGL((k_ex_scan_chunked<true>), dim3(grid), dim3(CWG), 0, s, a);
+	}
+	launch_ex_section(a, fmt, huff, s);
+	ktime_begin(0, s);
+	if (huff)
+		launch_low_encode_huff_v1(a, s);
+	else
+		hipLaunchKernelGGL(k_low_encode_chunked, dim3(a.max_chunks), dim3(CWG), 0, s, a);
+	ktime_end(0, s);
 }
 
 void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s)

@@ -120,6 +120,10 @@ void ktime_end(int which, hipStream_t s);
 void launch_svb_encode(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s);      // v1: one workgroup per read
 void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s); // v2: chunks + look-back
 void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s);
+void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_t s);
+// pieces of the v1 pipeline reused by the chunked one (press_kernels.hip)
+void launch_ex_section(const BatchArgs &a, int fmt, bool huff, hipStream_t s);
+void launch_low_encode_huff_v1(const BatchArgs &a, hipStream_t s);
 void launch_svb_decode(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s);
 // exception-split encode: scan (+ qts redo for ex-zd) -> section -> one-byte / Huffman stream
 void launch_ex_encode(const BatchArgs &a, int fmt, bool huff, hipStream_t s);

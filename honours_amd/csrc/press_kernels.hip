@@ -593,6 +593,7 @@ __global__ __launch_bounds__(64) void k_ex_section(BatchArgs a, int fmt, int huf
 	m->hdr = hdr;
 	m->status = 1;
 	m->seclen = 0;
+	a.out_len[r] = FAIL64; // until proven to fit
 	if (n == 0)
 		return; // the reference reads zd[0] of an empty array: outside its domain
 
@@ -663,6 +664,8 @@ __global__ __launch_bounds__(64) void k_ex_section(BatchArgs a, int fmt, int huf
 	m->seclen = (uint32_t) seclen;
 	m->nlow = (uint32_t) nlow;
 	m->status = 0;
+	if (!huff)
+		a.out_len[r] = (uint64_t) hdr + seclen + nlow; // the Huffman pass B knows its own length
 }
 
 // ------------------------------------------------------------------ exception split: pass B (one-byte stream)
@@ -1423,6 +1426,16 @@ void launch_svb_decode(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s
 	else
 		hipLaunchKernelGGL((k_svb_decode<false, false>), grid, block, 0, s, a);
 	ktime_end(1, s);
+}
+
+void launch_ex_section(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_ex_section, dim3(a.nreads), dim3(64), 0, s, a, fmt, huff ? 1 : 0);
+}
+
+void launch_low_encode_huff_v1(const BatchArgs &a, hipStream_t s)
+{
+	hipLaunchKernelGGL((k_low_encode<true>), dim3(a.nreads), dim3(WG), 0, s, a);
 }
 
 void launch_ex_encode(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
