@@ -1065,8 +1065,15 @@ constexpr uint32_t HEND = 0xFFFFFFFFu;  // "no further code": end of input or an
 
 // decode the codes that start in [s, sub_end); returns where the next one starts.
 // lbits: LDS dwords of the tile, lbase = bit position of lbits[0]
+// LDS image of the tile's bits, transposed: dword j of the tile lives at LIDX(j), so that the
+// 64 lanes of a wave - whose read positions are one subsequence (D dwords) apart - hit
+// consecutive banks instead of every D-th one
+constexpr int HROW = 576;  // >= HT + a few, multiple of 64
+// D = dwords per subsequence = 1 << dsh
+__device__ __forceinline__ uint32_t lidx(uint32_t j, uint32_t dsh) { return (j & ((1u << dsh) - 1u)) * HROW + (j >> dsh); }
+
 template <bool WRITE>
-__device__ __forceinline__ uint32_t huff_sub(const uint32_t *lbits, uint32_t lbase, const uint16_t *lut,
+__device__ __forceinline__ uint32_t huff_sub(const uint32_t *lbits, uint32_t lbase, uint32_t D, const uint16_t *lut,
 					     const uint16_t *lut2, const uint16_t *l2off, const uint8_t *l2bits,
 					     const HuffDev *hd, uint32_t s, uint32_t sub_end, uint32_t nbits,
 					     uint32_t &cnt, uint8_t *dst, uint32_t maxw)
@@ -1077,7 +1084,7 @@ __device__ __forceinline__ uint32_t huff_sub(const uint32_t *lbits, uint32_t lba
 		if (p >= nbits)
 			return HEND;
 		const uint32_t lp = p - lbase;
-		const uint64_t wnd = ((uint64_t) lbits[(lp >> 5) + 1] << 32 | lbits[lp >> 5]) >> (lp & 31);
+		const uint64_t wnd = ((uint64_t) lbits[lidx((lp >> 5) + 1, D)] << 32 | lbits[lidx(lp >> 5, D)]) >> (lp & 31);
 		uint32_t e = lut[(uint32_t) wnd & ((1u << HUF_LUT_BITS) - 1u)];
 		uint32_t sym, len;
 		if (e >= 0x8000u && e != 0xFFFFu) { // long code: second-level table
@@ -1127,7 +1134,7 @@ __global__ __launch_bounds__(HT) void k_huff_decode_par(DecodeArgs a)
 	__shared__ uint16_t lut2[HUF_L2_ENTRIES];
 	__shared__ uint16_t l2off[256];
 	__shared__ uint8_t l2bits[256];
-	__shared__ __attribute__((aligned(16))) uint32_t lbits[HT * 4 + 8];
+	__shared__ __attribute__((aligned(16))) uint32_t lbits[4 * HROW];
 	__shared__ uint32_t sE[HT];
 	__shared__ uint32_t sC[HT];
 	__shared__ uint32_t wtot[HT / 64];
@@ -1153,7 +1160,10 @@ __global__ __launch_bounds__(HT) void k_huff_decode_par(DecodeArgs a)
 	const uint32_t want = m->nlow;
 	uint8_t *low = a.low + a.off[r];
 	const uint32_t minlen = a.huff->minlen;
-	const uint32_t S = minlen >= 4 ? 128u : 32u * minlen; // bits per subsequence (>= the longest code, 24)
+	// bits per subsequence: at most HSYM = 32 codes start in one, and it is >= the longest code (24)
+	// (1024 threads x 64-bit subsequences was measured 1.7x slower than 512 x 128)
+	const uint32_t D = minlen >= 4 ? 2u : minlen >= 2 ? 1u : 0u; // log2(dwords per subsequence)
+	const uint32_t S = 32u << D;
 	const uint32_t tid = threadIdx.x;
 
 	// output FIFO state (see fifo_flush): obuf[0] <-> global address g (16-byte aligned)
@@ -1179,7 +1189,7 @@ __global__ __launch_bounds__(HT) void k_huff_decode_par(DecodeArgs a)
 					if (b + q < nbytes)
 						v |= (uint32_t) h[b + q] << (8 * q);
 			}
-			lbits[j] = v;
+			lbits[lidx(j, D)] = v;
 		}
 		__syncthreads();
 
@@ -1192,7 +1202,7 @@ __global__ __launch_bounds__(HT) void k_huff_decode_par(DecodeArgs a)
 		const uint32_t sub_end = sub0 + S;
 		uint32_t start = sub0;
 		uint32_t cnt;
-		uint32_t e = huff_sub<false>(lbits, lbase, lut, lut2, l2off, l2bits, a.huff, start, sub_end, nbits, cnt, nullptr, 0);
+		uint32_t e = huff_sub<false>(lbits, lbase, D, lut, lut2, l2off, l2bits, a.huff, start, sub_end, nbits, cnt, nullptr, 0);
 		sE[tid] = e;
 		sC[tid] = cnt;
 		for (;;) {
@@ -1216,7 +1226,7 @@ __global__ __launch_bounds__(HT) void k_huff_decode_par(DecodeArgs a)
 					e = HEND;
 					cnt = 0;
 				} else {
-					e = huff_sub<false>(lbits, lbase, lut, lut2, l2off, l2bits, a.huff, start, sub_end, nbits, cnt, nullptr, 0);
+					e = huff_sub<false>(lbits, lbase, D, lut, lut2, l2off, l2bits, a.huff, start, sub_end, nbits, cnt, nullptr, 0);
 				}
 				sE[tid] = e;
 				sC[tid] = cnt;
@@ -1252,7 +1262,7 @@ __global__ __launch_bounds__(HT) void k_huff_decode_par(DecodeArgs a)
 		// ---- final pass: symbols into the LDS FIFO
 		if (cnt && maxw && start != HEND) {
 			uint32_t c2;
-			(void) huff_sub<true>(lbits, lbase, lut, lut2, l2off, l2bits, a.huff, start, sub_end, nbits, c2, obuf + fill + excl, maxw);
+			(void) huff_sub<true>(lbits, lbase, D, lut, lut2, l2off, l2bits, a.huff, start, sub_end, nbits, c2, obuf + fill + excl, maxw);
 		}
 		const uint32_t last_e = sE[HT - 1];
 		__syncthreads();
