@@ -498,7 +498,8 @@ static int launch_depress(int method, const DecodeArgs &a, hipStream_t s)
 	case PRESS_HIP_SVB12_ZD: v1 ? launch_svb_decode(a, false, true, s) : launch_svb_decode_chunked(a, false, true, s); break;
 	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_decode(a, true, true, s) : launch_svb_decode_chunked(a, true, true, s); break;
 	default:
-		launch_ex_decode(a, exfmt_of(method), is_shuff(method), s);
+		v1 ? launch_ex_decode(a, exfmt_of(method), is_shuff(method), s)
+		   : launch_ex_decode_chunked(a, exfmt_of(method), is_shuff(method), s);
 	}
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess)

@@ -1179,6 +1179,293 @@ __global__ __launch_bounds__(CWG) void k_low_encode_chunked(BatchArgs a)
 	}
 }
 
+// ------------------------------------------------------------------ exception split decode, chunked
+//
+// Second half of vbe21_depress and siblings (press.c:2757-2771) fused with unzigdelta_u16_16
+// (trans.c:260), after k_ex_parse has produced the sorted exception list (and, for the
+// Huffman variants, k_huff_decode_par the one-byte stream).  Sample i >= 1 is exception e
+// if pos[e] == i-1, otherwise one-byte value number (i-1) - #exceptions before it; so a
+// chunk finds its place in the stream by binary search - only the running sample value
+// needs the look-back chain.
+
+// chunk table from the parsed streams: n = 1 + nlow + nex samples per read
+__global__ __launch_bounds__(256) void k_chunk_prep_meta(const uint64_t *off, const uint64_t *in_off,
+							 const ReadMeta *meta, uint32_t nreads, ChunkDesc *chunks,
+							 uint64_t *gran, ChunkCtl *ctl, uint32_t max_chunks,
+							 uint32_t *out_n)
+{
+	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	uint32_t n = 0, nch = 0;
+	if (r < nreads && !meta[r].status) {
+		n = 1u + meta[r].nlow + meta[r].nex;
+		nch = (n + CHUNK - 1) / CHUNK;
+	}
+	const uint32_t inc = wave_incl_scan32(nch);
+	uint32_t base = 0;
+	if ((threadIdx.x & 63) == 63 && inc)
+		base = atomicAdd(&ctl->nchunks, inc);
+	base = (uint32_t) __builtin_amdgcn_readlane((int) base, 63);
+	const uint32_t first = base + inc - nch;
+	if (r >= nreads)
+		return;
+	out_n[r] = n ? n : CFAIL32;
+	for (uint32_t j = 0; j < nch && first + j < max_chunks; j++) {
+		ChunkDesc d;
+		d.sig_off = off[r];
+		d.out_base = in_off[r];
+		d.n = n;
+		d.j = j;
+		d.read = r;
+		d.cap_ok = 1;
+		d.ebefore = 0;
+		d.ecnt[0] = d.ecnt[1] = d.ecnt[2] = d.ecnt[3] = 0;
+		d.kmask[0] = d.kmask[1] = d.kmask[2] = d.kmask[3] = 0;
+		chunks[first + j] = d;
+		gran[first + j] = 0;
+	}
+}
+
+__device__ __forceinline__ uint32_t lower_bound_dev(const uint32_t *p, uint32_t n, uint32_t key)
+{
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (p[mid] < key)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	return lo;
+}
+
+// slow path of one sub-tile: values of the lane's 8 samples, exceptions merged in
+__device__ __forceinline__ void gather_low(const uint8_t *low, uint32_t nlow, const uint32_t *pos,
+					   const uint32_t *val, uint32_t nex, uint32_t zd0, uint32_t i0,
+					   uint32_t n, uint32_t v[4])
+{
+	v[0] = v[1] = v[2] = v[3] = 0;
+	if (i0 >= n)
+		return;
+	const uint32_t nv = min(8u, n - i0);
+	const uint32_t uf = i0 ? i0 - 1 : 0;
+	uint32_t e = lower_bound_dev(pos, nex, uf);
+	uint32_t l = uf - e; // index of the next one-byte value
+	uint32_t nextpos = e < nex ? pos[e] : 0xFFFFFFFFu;
+#pragma unroll
+	for (int h = 0; h < 8; h++) {
+		if ((uint32_t) h < nv) {
+			const uint32_t i = i0 + h;
+			uint32_t z;
+			if (i == 0) {
+				z = zd0;
+			} else if (i - 1 == nextpos) {
+				z = val[e] & 0xFFFFu;
+				e++;
+				nextpos = e < nex ? pos[e] : 0xFFFFFFFFu;
+			} else {
+				z = l < nlow ? low[l] : 0u;
+				l++;
+			}
+			v[h >> 1] |= z << (16 * (h & 1));
+		}
+	}
+}
+
+template <bool HUFF>
+__global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
+{
+	__shared__ uint32_t s_ticket;
+	__shared__ uint32_t s_wsum[4];
+	__shared__ uint32_t s_sbase;
+	__shared__ uint16_t s_xl[4][CK][64];
+	__shared__ uint32_t s_sub[4][CK];  // delta total / base per sub-tile
+	__shared__ uint32_t s_cnt[4][CK];  // exceptions per sub-tile, then their exclusive prefix
+	__shared__ uint32_t s_km[4];
+
+	const int lane = threadIdx.x & 63;
+	const int w = (int) uni(threadIdx.x >> 6);
+	if (threadIdx.x == 0)
+		s_ticket = atomicAdd(&a.ctl->ticket, 1u);
+	if (lane < CK)
+		s_cnt[w][lane] = 0;
+	if (lane == 0)
+		s_km[w] = 0;
+	__syncthreads();
+	const uint32_t t = uni(s_ticket);
+	if (t >= a.ctl->nchunks)
+		return;
+	const ChunkU d = load_chunk(a.chunks + t);
+	const uint32_t n = d.n;
+	const uint32_t first = d.j * CHUNK;
+	const bool last = first + CHUNK >= n;
+	const ReadMeta *m = a.meta + d.read;
+	const uint32_t nex = uni(m->nex), nlow = uni(m->nlow), zd0 = uni(m->zd0);
+	const int q = (int) uni(m->q);
+	const uint32_t *pos = a.ex_pos + d.sig_off;
+	const uint32_t *val = a.ex_val + d.sig_off;
+	const uint8_t *low = HUFF ? a.low + d.sig_off : a.in + d.out_base + uni(m->hdr) + uni(m->seclen);
+	int16_t *out = a.sig + d.sig_off;
+	const uint32_t ws = first + w * WAVE_SAMPLES;
+	const uint32_t nsub = ws >= n ? 0u : min((uint32_t) CK, (n - ws + SUB - 1) / SUB);
+	const uint32_t live = (1u << nsub) - 1u;
+
+	// ---- exceptions of this wave's quarter: which sub-tiles hold one, how many before each
+	uint32_t e_lo = 0;
+	if (nsub) {
+		const uint32_t wend = min(ws + WAVE_SAMPLES, n);
+		e_lo = lower_bound_dev(pos, nex, ws ? ws - 1 : 0);
+		const uint32_t e_hi = lower_bound_dev(pos, nex, wend - 1);
+		for (uint32_t e = e_lo + lane; e < e_hi; e += 64) {
+			const uint32_t k = (pos[e] + 1 - ws) / SUB;
+			atomicAdd(&s_cnt[w][k], 1u);
+			atomicOr(&s_km[w], 1u << k);
+		}
+	}
+	wave_lds_sync();
+	uint32_t kmask = uni(s_km[w]);
+	if (ws == 0)
+		kmask |= 1u; // sample 0 comes from the header
+	if ((n & 7) && n > ws && n - ws <= WAVE_SAMPLES)
+		kmask |= 1u << ((n - 1 - ws) / SUB); // ragged tail
+	if (lane < CK) {
+		const uint32_t c = s_cnt[w][lane];
+		const uint32_t inc = wave_incl_scan_dpp(c);
+		s_cnt[w][lane] = inc - c;
+	}
+	wave_lds_sync();
+	// sub-tiles whose 8-byte windows could reach past the one-byte stream are not plain
+#pragma unroll
+	for (int k = 0; k < CK; k++)
+		if (((live >> k) & 1u) && (uint64_t) ws + k * SUB + SUB + 8 > (uint64_t) nlow + 1 + e_lo)
+			kmask |= 1u << k;
+	kmask &= live;
+	const uint32_t plain = live & ~kmask;
+
+	// ---- phase 1: one-byte values of the plain sub-tiles (8 per lane, any alignment)
+	uint2 dat[CK];
+#pragma unroll
+	for (int k = 0; k < CK; k++) {
+		const uint32_t i0 = ws + k * SUB + lane * 8;
+		uint2 dd = make_uint2(0, 0);
+		if ((plain >> k) & 1u) {
+			const uint32_t eb = e_lo + uni(s_cnt[w][k]);
+			if (i0 < n)
+				__builtin_memcpy(&dd, low + (i0 - 1 - eb), 8);
+		}
+		dat[k] = dd;
+	}
+
+	// ---- phase 2: delta sums
+#pragma unroll
+	for (int k = 0; k < CK; k++) {
+		if ((plain >> k) & 1u) {
+			uint32_t v[4];
+			expand8(dat[k], v);
+			uint32_t acc = 0;
+#pragma unroll
+			for (int h = 0; h < 4; h++)
+				acc = pk_add16(acc, unzz_pair(v[h]));
+			const uint32_t tot16 = (acc + (acc >> 16)) & 0xFFFFu;
+			const uint32_t inc = wave_incl_scan_dpp(tot16);
+			s_xl[w][k][lane] = (uint16_t) (inc - tot16);
+			if (lane == 63)
+				s_sub[w][k] = inc;
+		}
+	}
+	for (uint32_t mm = kmask; mm; mm &= mm - 1) {
+		const uint32_t k = (uint32_t) __builtin_ctz(mm);
+		uint32_t v[4];
+		gather_low(low, nlow, pos, val, nex, zd0, ws + k * SUB + lane * 8, n, v);
+		uint32_t acc = 0;
+#pragma unroll
+		for (int h = 0; h < 4; h++)
+			acc = pk_add16(acc, unzz_pair(v[h]));
+		const uint32_t tot16 = (acc + (acc >> 16)) & 0xFFFFu;
+		const uint32_t inc = wave_incl_scan_dpp(tot16);
+		s_xl[w][k][lane] = (uint16_t) (inc - tot16);
+		if (lane == 63)
+			s_sub[w][k] = inc;
+	}
+	wave_lds_sync();
+	uint32_t wtot = 0;
+	{
+		const uint32_t v = (lane < (int) nsub) ? s_sub[w][lane < CK ? lane : 0] : 0u;
+		const uint32_t inc = wave_incl_scan_dpp(v);
+		wave_lds_sync();
+		if (lane < CK)
+			s_sub[w][lane] = inc - v;
+		wtot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+	}
+	wave_lds_sync();
+	if (lane == 0)
+		s_wsum[w] = wtot & 0xFFFFu;
+	__syncthreads();
+	const uint32_t u0 = uni(s_wsum[0]), u1 = uni(s_wsum[1]), u2 = uni(s_wsum[2]), u3 = uni(s_wsum[3]);
+	if (w == 0) {
+		const uint32_t sv = (uint32_t) lookback(a.gran, t, d.j, (uint64_t) ((u0 + u1 + u2 + u3) & 0xFFFFu), last);
+		if (lane == 0)
+			s_sbase = sv;
+	}
+	__syncthreads();
+	const uint32_t sb = uni(s_sbase) + (w > 0 ? u0 : 0u) + (w > 1 ? u1 : 0u) + (w > 2 ? u2 : 0u);
+
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+	for (int k = 0; k < CK; k++)
+		asm volatile("" : "+v"(dat[k].x), "+v"(dat[k].y));
+
+	// ---- phase 3: values, prefix inside the lane, bases, ex-zd shift, store
+	const u16x2 qq = { (unsigned short) q, (unsigned short) q };
+#pragma unroll
+	for (int k = 0; k < CK; k++) {
+		const uint32_t i0 = ws + k * SUB + lane * 8;
+		if ((plain >> k) & 1u) {
+			uint32_t v[4];
+			expand8(dat[k], v);
+#pragma unroll
+			for (int h = 0; h < 4; h++)
+				v[h] = unzz_pair(v[h]);
+			(void) lane_prefix8(v);
+			const uint32_t b16 = (sb + uni(s_sub[w][k]) + s_xl[w][k][lane]) & 0xFFFFu;
+			const uint32_t b2 = b16 | (b16 << 16);
+#pragma unroll
+			for (int h = 0; h < 4; h++) {
+				v[h] = pk_add16(v[h], b2);
+				if (q) // ex_zd.c:396 do_rev_qts_inplace
+					v[h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, v[h]) << qq);
+			}
+			if (i0 < n)
+				*reinterpret_cast<uint4 *>(out + i0) = make_uint4(v[0], v[1], v[2], v[3]);
+		}
+	}
+	for (uint32_t mm = kmask; mm; mm &= mm - 1) {
+		const uint32_t k = (uint32_t) __builtin_ctz(mm);
+		const uint32_t i0 = ws + k * SUB + lane * 8;
+		uint32_t v[4];
+		gather_low(low, nlow, pos, val, nex, zd0, i0, n, v);
+#pragma unroll
+		for (int h = 0; h < 4; h++)
+			v[h] = unzz_pair(v[h]);
+		(void) lane_prefix8(v);
+		const uint32_t b16 = (sb + uni(s_sub[w][k]) + s_xl[w][k][lane]) & 0xFFFFu;
+		const uint32_t b2 = b16 | (b16 << 16);
+#pragma unroll
+		for (int h = 0; h < 4; h++) {
+			v[h] = pk_add16(v[h], b2);
+			if (q)
+				v[h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, v[h]) << qq);
+		}
+		if (i0 + 8 <= n) {
+			*reinterpret_cast<uint4 *>(out + i0) = make_uint4(v[0], v[1], v[2], v[3]);
+		} else if (i0 < n) {
+#pragma unroll
+			for (uint32_t h = 0; h < 8; h++)
+				if (h < n - i0)
+					out[i0 + h] = (int16_t) (v[h >> 1] >> (16 * (h & 1)));
+		}
+	}
+}
+
 // ------------------------------------------------------------------ launchers
 
 template <bool KEY2, bool ZD>
@@ -1250,6 +1537,25 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_
 	else
 		hipLaunchKernelGGL(k_low_encode_chunked, dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	ktime_end(0, s);
+}
+
+// exception-split decode: parse + (Huffman) from press_kernels.hip, then the chunked merge
+void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, bool huff, hipStream_t s)
+{
+	if (!a.nreads || !a.max_chunks)
+		return;
+	launch_ex_parse_huff(a, fmt, huff, s);
+	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
+	hipLaunchKernelGGL(k_chunk_prep_meta, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off, a.in_off,
+			   a.meta, a.nreads, a.chunks, a.gran, a.ctl, a.max_chunks, a.out_n);
+	if (!huff)
+		ktime_begin(1, s);
+	if (huff)
+		hipLaunchKernelGGL((k_low_decode_chunked<true>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
+	else
+		hipLaunchKernelGGL((k_low_decode_chunked<false>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
+	if (!huff)
+		ktime_end(1, s);
 }
 
 void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s)

@@ -121,6 +121,8 @@ void launch_svb_encode(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s)
 void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s); // v2: chunks + look-back
 void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s);
 void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_t s);
+void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, bool huff, hipStream_t s);
+void launch_ex_parse_huff(const DecodeArgs &a, int fmt, bool huff, hipStream_t s); // press_kernels.hip
 // pieces of the v1 pipeline reused by the chunked one (press_kernels.hip)
 void launch_ex_section(const BatchArgs &a, int fmt, bool huff, hipStream_t s);
 void launch_low_encode_huff_v1(const BatchArgs &a, hipStream_t s);

@@ -1465,6 +1465,22 @@ void launch_ex_encode(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
 	ktime_end(0, s);
 }
 
+// k_ex_parse and, for the Huffman variants, the stream decode into a.low (timed as the
+// dominant kernel of those methods)
+void launch_ex_parse_huff(const DecodeArgs &a, int fmt, bool huff, hipStream_t s)
+{
+	const bool huff_parallel = getenv("PRESS_HIP_HUFF_SERIAL") == nullptr;
+	hipLaunchKernelGGL(k_ex_parse, dim3(a.nreads), dim3(64), 0, s, a, fmt, huff ? 1 : 0);
+	if (huff) {
+		ktime_begin(1, s);
+		if (huff_parallel)
+			hipLaunchKernelGGL(k_huff_decode_par, dim3(a.nreads), dim3(HT), 0, s, a);
+		else
+			hipLaunchKernelGGL(k_huff_decode, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a);
+		ktime_end(1, s);
+	}
+}
+
 void launch_ex_decode(const DecodeArgs &a, int fmt, bool huff, hipStream_t s)
 {
 	const bool huff_parallel = getenv("PRESS_HIP_HUFF_SERIAL") == nullptr;
