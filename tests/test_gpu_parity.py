@@ -128,6 +128,32 @@ def test_random_vs_oracle(oracle, m):
         check_read(oracle, m, s)
 
 
+@pytest.mark.parametrize("m", DET)
+def test_multi_chunk_reads(oracle, m):
+    """reads longer than one 32768-sample chunk: exceptions on both sides of chunk and
+    wave-quarter boundaries, exception-dense stretches, ragged ends, q > 0"""
+    rng = np.random.default_rng(abs(hash("mc" + m)) % (1 << 31))
+    for it, n in enumerate([32767, 32768, 32769, 40961, 65536, 65543, 100003, 131072 + 17]):
+        exr = [0.0005, 0.0, 0.01, 0.08][it % 4]
+        d = rng.integers(-60, 60, size=n)
+        ex = rng.random(n) < exr
+        # make sure the boundaries themselves are hit
+        for b in (8191, 8192, 8193, 32767, 32768, 32769, 65535, 65536):
+            if b < n and it % 2 == 0:
+                ex[b] = True
+        d[ex] = rng.integers(-30000, 30000, size=int(ex.sum()))
+        s = (np.cumsum(d) + 500).astype(np.int64).astype(np.uint16).view(np.int16)
+        if it == 3:
+            s = ((s >> 2) << 2).astype(np.int16)  # q = 2 for ex-zd
+        if m.startswith("shuffman") and not shuff_ok(m, s):
+            continue
+        ret, want = oracle.press(m, s, cap=int(oracle.bound(m, n)) + 6 * n + 1024)
+        assert ret == 0
+        if m.startswith("shuffman") and m != "shuffman_vbe21_zd" and len(want) > 60000 and exr > 0.005:
+            continue  # press.c:4520: the b/sb/ss variants keep the section length in 16 bits
+        check_read(oracle, m, s, want)
+
+
 @pytest.mark.parametrize("m", ZSTD)
 def test_zstd_compositions(oracle, m):
     """inner stream on the GPU, libzstd on the host: round trip + the oracle's decoder
