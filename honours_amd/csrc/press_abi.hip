@@ -249,6 +249,23 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 				h.lut2[h.l2off[id] + i] = (uint16_t) (s | (len[s] << 8));
 		}
 	}
+	// two-symbol table
+	for (uint32_t i = 0; i < (1u << HUF_LUT_BITS); i++) {
+		const uint16_t e1 = h.lut[i];
+		if (e1 == 0xFFFFu) {
+			h.lut32[i] = 0xFFFFFFFFu;
+		} else if (e1 & 0x8000u) {
+			h.lut32[i] = HUF_LONG | (e1 & 0xFFu);
+		} else {
+			const uint32_t s1 = e1 & 0xFFu, l1 = e1 >> 8;
+			uint32_t v = s1 | (l1 << 16) | (l1 << 20);
+			const uint32_t rest = (uint32_t) HUF_LUT_BITS - l1;
+			const uint16_t e2 = h.lut[i >> l1]; // the upper bits are zeros, not stream bits:
+			if (e2 != 0xFFFFu && !(e2 & 0x8000u) && (uint32_t) (e2 >> 8) <= rest) // only a code that fits counts
+				v = s1 | ((uint32_t) (e2 & 0xFFu) << 8) | (l1 << 16) | ((l1 + (e2 >> 8)) << 20) | HUF_TWO;
+			h.lut32[i] = v;
+		}
+	}
 	h.minlen = 64;
 	h.maxlen = 0;
 	for (int s = 0; s < 256; s++) {

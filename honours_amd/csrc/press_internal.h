@@ -42,7 +42,13 @@ struct HuffDev {
 	uint16_t lut2[HUF_L2_ENTRIES];
 	uint16_t l2off[256];
 	uint8_t l2bits[256];
+	// two-symbol first level for the parallel decoder: sym1 | sym2 << 8 | len1 << 16 |
+	// (len1 + len2) << 20 | HUF_TWO when two whole codes fit in HUF_LUT_BITS bits;
+	// HUF_LONG | id for a long code's prefix; 0xFFFFFFFF: walk the trie
+	uint32_t lut32[1 << HUF_LUT_BITS];
 };
+constexpr uint32_t HUF_TWO = 1u << 28;
+constexpr uint32_t HUF_LONG = 1u << 30;
 
 // ---- chunked (v2) svb kernels: a read is cut into chunks of CHUNK samples, one workgroup
 // per chunk; chunks of a read are chained by a decoupled look-back over 8-byte granules.

@@ -1073,7 +1073,7 @@ constexpr int HROW = 576;  // >= HT + a few, multiple of 64
 __device__ __forceinline__ uint32_t lidx(uint32_t j, uint32_t dsh) { return (j & ((1u << dsh) - 1u)) * HROW + (j >> dsh); }
 
 template <bool WRITE>
-__device__ __forceinline__ uint32_t huff_sub(const uint32_t *lbits, uint32_t lbase, uint32_t D, const uint16_t *lut,
+__device__ __forceinline__ uint32_t huff_sub(const uint32_t *lbits, uint32_t lbase, uint32_t D, const uint32_t *lut,
 					     const uint16_t *lut2, const uint16_t *l2off, const uint8_t *l2bits,
 					     const HuffDev *hd, uint32_t s, uint32_t sub_end, uint32_t nbits,
 					     uint32_t &cnt, uint8_t *dst, uint32_t maxw)
@@ -1084,23 +1084,38 @@ __device__ __forceinline__ uint32_t huff_sub(const uint32_t *lbits, uint32_t lba
 		if (p >= nbits)
 			return HEND;
 		const uint32_t lp = p - lbase;
-		const uint64_t wnd = ((uint64_t) lbits[lidx((lp >> 5) + 1, D)] << 32 | lbits[lidx(lp >> 5, D)]) >> (lp & 31);
-		uint32_t e = lut[(uint32_t) wnd & ((1u << HUF_LUT_BITS) - 1u)];
+		// 32 stream bits from position p (codes are at most 24 bits long)
+		const uint32_t wnd = __builtin_amdgcn_alignbit(lbits[lidx((lp >> 5) + 1, D)], lbits[lidx(lp >> 5, D)], lp & 31);
+		uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
 		uint32_t sym, len;
-		if (e >= 0x8000u && e != 0xFFFFu) { // long code: second-level table
-			const uint32_t id = e & 0xFFu;
-			e = lut2[l2off[id] + ((uint32_t) (wnd >> HUF_LUT_BITS) & ((1u << l2bits[id]) - 1u))];
-			if (e == 0xFFFFu)
-				return HEND; // no such code
-		}
-		if (e != 0xFFFFu) {
+		if (e < HUF_LONG) {
+			// one or two whole codes inside the 12-bit window
+			const uint32_t l1 = (e >> 16) & 0xFu, l12 = (e >> 20) & 0x1Fu;
+			if ((e & HUF_TWO) && p + l1 < sub_end && p + l12 <= nbits) {
+				if (WRITE) {
+					if (cnt < maxw)
+						dst[cnt] = (uint8_t) e;
+					if (cnt + 1 < maxw)
+						dst[cnt + 1] = (uint8_t) (e >> 8);
+				}
+				cnt += 2;
+				p += l12;
+				continue;
+			}
 			sym = e & 0xFFu;
-			len = e >> 8;
+			len = l1;
+		} else if (e != 0xFFFFFFFFu) { // long code: second-level table
+			const uint32_t id = e & 0xFFu;
+			const uint32_t e2 = lut2[l2off[id] + ((wnd >> HUF_LUT_BITS) & ((1u << l2bits[id]) - 1u))];
+			if (e2 == 0xFFFFu)
+				return HEND; // no such code
+			sym = e2 & 0xFFu;
+			len = e2 >> 8;
 		} else {
 			int node = 0;
 			len = 0;
 			while (node >= 0 && hd->leaf[node] < 0 && len < 32) {
-				node = hd->child[node][(uint32_t) (wnd >> len) & 1u];
+				node = hd->child[node][(wnd >> len) & 1u];
 				len++;
 			}
 			if (node < 0 || hd->leaf[node] < 0)
@@ -1130,7 +1145,7 @@ extern "C" int press_hip_debug_huff(unsigned long long *dst)
 
 __global__ __launch_bounds__(HT) void k_huff_decode_par(DecodeArgs a)
 {
-	__shared__ uint16_t lut[1 << HUF_LUT_BITS];
+	__shared__ uint32_t lut[1 << HUF_LUT_BITS];
 	__shared__ uint16_t lut2[HUF_L2_ENTRIES];
 	__shared__ uint16_t l2off[256];
 	__shared__ uint8_t l2bits[256];
@@ -1145,7 +1160,7 @@ __global__ __launch_bounds__(HT) void k_huff_decode_par(DecodeArgs a)
 	if (m->status)
 		return;
 	for (uint32_t i = threadIdx.x; i < (1u << HUF_LUT_BITS); i += HT)
-		lut[i] = a.huff->lut[i];
+		lut[i] = a.huff->lut32[i];
 	for (uint32_t i = threadIdx.x; i < (uint32_t) HUF_L2_ENTRIES; i += HT)
 		lut2[i] = a.huff->lut2[i];
 	if (threadIdx.x < 256) {
