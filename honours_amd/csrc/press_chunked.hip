@@ -1005,6 +1005,14 @@ __device__ __forceinline__ uint32_t exc_mask(const uint4 &z, uint32_t i0)
 	return m;
 }
 
+// ex-zd: does any read of the batch need the second scan (all samples divisible by 2^q, q > 0)?
+__global__ __launch_bounds__(256) void k_ex_redo_flag(BatchArgs a)
+{
+	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r < a.nreads && a.nsamp[r] && !(a.meta[r].ored & 1u))
+		atomicOr(&a.ctl->pad0[0], 1u);
+}
+
 template <bool REDO>
 __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 {
@@ -1012,6 +1020,8 @@ __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 	__shared__ uint32_t s_wtot[4];
 	__shared__ uint64_t s_excl;
 
+	if (REDO && uni(a.ctl->pad0[0]) == 0)
+		return; // no read of this batch has q > 0 (the common case)
 	const uint32_t nchunks = uni(a.ctl->nchunks);
 	const int lane = threadIdx.x & 63;
 	const int w = (int) uni(threadIdx.x >> 6);
@@ -1526,6 +1536,7 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_
 	hipLaunchKernelGGL((k_ex_scan_chunked<false>), dim3(grid), dim3(CWG), 0, s, a);
 	if (fmt == EXF_EXZD) {
 		// second scan on the shifted samples for reads with q > 0 (fresh tickets and granules)
+		hipLaunchKernelGGL(k_ex_redo_flag, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a);
 		(void) hipMemsetAsync(&a.ctl->ticket, 0, sizeof(uint32_t), s);
 		(void) hipMemsetAsync(a.gran, 0, (size_t) a.max_chunks * sizeof(uint64_t), s);
 		hipLaunchKernelGGL((k_ex_scan_chunked<true>), dim3(grid), dim3(CWG), 0, s, a);
