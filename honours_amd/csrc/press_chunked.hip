@@ -34,6 +34,7 @@ constexpr uint32_t SUB = 512;                // samples per sub-tile (64 lanes x
 constexpr uint32_t WAVE_SAMPLES = CK * SUB;  // 8192
 static_assert(WAVE_SAMPLES * 4 == CHUNK, "chunk = 4 waves");
 
+constexpr uint32_t PERSISTENT_GRID = 2048;   // workgroups of the ticket-loop kernels
 constexpr uint64_t G_A = 1ull << 62;         // granule: aggregate of this chunk only
 constexpr uint64_t G_P = 2ull << 62;         // granule: inclusive prefix up to this chunk
 constexpr uint64_t G_MASK = (1ull << 62) - 1;
@@ -357,20 +358,14 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 			// fast path: no exception, no ragged tail in the whole sub-tile (lanes are
 			// either complete or entirely beyond the end of the read)
 			if (i0 < n) {
-#ifndef EXP_NO_KEYS
 				if (!KEY2)
 					out[i0 >> 3] = 0;
 				else
 					__builtin_memset(out + (i0 >> 2), 0, 2);
-#endif
 				uint2 v;
 				v.x = lo0;
 				v.y = lo1;
-#ifndef EXP_NO_DATA
 				__builtin_memcpy(data + ebase + i0, &v, 8);
-#else
-				if (lo0 == 0x12345678 && lo1 == 0x9abcdef0) __builtin_memcpy(data + ebase + i0, &v, 8);
-#endif
 			}
 			continue;
 		}
@@ -1486,10 +1481,7 @@ static void run_encode(const BatchArgs &a, hipStream_t s)
 			   a.nsamp, a.out_off, (const uint64_t *) nullptr, a.nreads, a.chunks, a.gran, a.ctl,
 			   a.max_chunks, a.out_len, (uint32_t *) nullptr, (uint32_t *) nullptr);
 	// persistent grid: enough workgroups to fill the chip twice over (4 resident per CU)
-#ifndef EXP_GRID
-#define EXP_GRID 2048u
-#endif
-	const uint32_t grid = a.max_chunks < EXP_GRID ? a.max_chunks : EXP_GRID;
+	const uint32_t grid = a.max_chunks < PERSISTENT_GRID ? a.max_chunks : PERSISTENT_GRID;
 	ktime_begin(0, s);
 	hipLaunchKernelGGL((k_svb_encode_chunked<KEY2, ZD>), dim3(grid), dim3(CWG), 0, s, a);
 	ktime_end(0, s);
@@ -1528,7 +1520,7 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_
 {
 	if (!a.nreads || !a.max_chunks)
 		return;
-	const uint32_t grid = a.max_chunks < EXP_GRID ? a.max_chunks : EXP_GRID;
+	const uint32_t grid = a.max_chunks < PERSISTENT_GRID ? a.max_chunks : PERSISTENT_GRID;
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL((k_chunk_prep<false, false>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
 			   a.nsamp, a.out_off, (const uint64_t *) nullptr, a.nreads, a.chunks, a.gran, a.ctl,
