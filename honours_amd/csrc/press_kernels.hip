@@ -1072,6 +1072,9 @@ constexpr int HROW = 576;  // >= HT + a few, multiple of 64
 // D = dwords per subsequence = 1 << dsh
 __device__ __forceinline__ uint32_t lidx(uint32_t j, uint32_t dsh) { return (j & ((1u << dsh) - 1u)) * HROW + (j >> dsh); }
 
+// The loop is wave-uniform (it runs while any lane still has a code to decode) and
+// predicated rather than branched: lanes of a wave need different numbers of iterations, and
+// per-lane branches cost more scalar/exec bookkeeping than the few masked operations.
 template <bool WRITE>
 __device__ __forceinline__ uint32_t huff_sub(const uint32_t *lbits, uint32_t lbase, uint32_t D, const uint32_t *lut,
 					     const uint16_t *lut2, const uint16_t *l2off, const uint8_t *l2bits,
@@ -1080,56 +1083,55 @@ __device__ __forceinline__ uint32_t huff_sub(const uint32_t *lbits, uint32_t lba
 {
 	uint32_t p = s;
 	cnt = 0;
-	while (p < sub_end) {
-		if (p >= nbits)
-			return HEND;
-		const uint32_t lp = p - lbase;
+	const uint32_t lim = sub_end < nbits ? sub_end : nbits; // codes must START below this
+	bool dead = false;                                      // ran into the end / an undecodable prefix
+	for (;;) {
+		const bool act = !dead && p < lim;
+		if (!__any(act))
+			break;
+		const uint32_t lp = act ? p - lbase : 0u;
 		// 32 stream bits from position p (codes are at most 24 bits long)
 		const uint32_t wnd = __builtin_amdgcn_alignbit(lbits[lidx((lp >> 5) + 1, D)], lbits[lidx(lp >> 5, D)], lp & 31);
-		uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
-		uint32_t sym, len;
-		if (e < HUF_LONG) {
-			// one or two whole codes inside the 12-bit window
-			const uint32_t l1 = (e >> 16) & 0xFu, l12 = (e >> 20) & 0x1Fu;
-			if ((e & HUF_TWO) && p + l1 < sub_end && p + l12 <= nbits) {
-				if (WRITE) {
-					if (cnt < maxw)
-						dst[cnt] = (uint8_t) e;
-					if (cnt + 1 < maxw)
-						dst[cnt + 1] = (uint8_t) (e >> 8);
+		const uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
+		uint32_t sym = e & 0xFFu, sym2 = (e >> 8) & 0xFFu;
+		uint32_t len = (e >> 16) & 0xFu;
+		const uint32_t l12 = (e >> 20) & 0x1Fu;
+		bool ok = true;
+		if (__any(act && e >= HUF_LONG)) { // rare: a code longer than 12 bits somewhere in the wave
+			if (act && e >= HUF_LONG) {
+				if (e != 0xFFFFFFFFu) {
+					const uint32_t id = e & 0xFFu;
+					const uint32_t e2 = lut2[l2off[id] + ((wnd >> HUF_LUT_BITS) & ((1u << l2bits[id]) - 1u))];
+					ok = e2 != 0xFFFFu;
+					sym = e2 & 0xFFu;
+					len = e2 >> 8;
+				} else {
+					int node = 0;
+					len = 0;
+					while (node >= 0 && hd->leaf[node] < 0 && len < 32) {
+						node = hd->child[node][(wnd >> len) & 1u];
+						len++;
+					}
+					ok = node >= 0 && hd->leaf[node] >= 0;
+					sym = ok ? (uint32_t) hd->leaf[node] : 0u;
 				}
-				cnt += 2;
-				p += l12;
-				continue;
 			}
-			sym = e & 0xFFu;
-			len = l1;
-		} else if (e != 0xFFFFFFFFu) { // long code: second-level table
-			const uint32_t id = e & 0xFFu;
-			const uint32_t e2 = lut2[l2off[id] + ((wnd >> HUF_LUT_BITS) & ((1u << l2bits[id]) - 1u))];
-			if (e2 == 0xFFFFu)
-				return HEND; // no such code
-			sym = e2 & 0xFFu;
-			len = e2 >> 8;
-		} else {
-			int node = 0;
-			len = 0;
-			while (node >= 0 && hd->leaf[node] < 0 && len < 32) {
-				node = hd->child[node][(wnd >> len) & 1u];
-				len++;
-			}
-			if (node < 0 || hd->leaf[node] < 0)
-				return HEND; // no such code
-			sym = (uint32_t) hd->leaf[node];
 		}
-		if (p + len > nbits)
-			return HEND; // the code runs off the end of the input
-		if (WRITE && cnt < maxw)
-			dst[cnt] = (uint8_t) sym;
-		cnt++;
-		p += len;
+		// two whole codes from one lookup when the second also starts in this subsequence
+		const bool two = act && e < HUF_LONG && (e & HUF_TWO) && p + len < lim && p + l12 <= nbits;
+		const bool one = act && !two && ok && p + len <= nbits;
+		if (act && !two && !one)
+			dead = true; // the code runs off the end of the input, or there is no such code
+		if (WRITE) {
+			if ((one || two) && cnt < maxw)
+				dst[cnt] = (uint8_t) sym;
+			if (two && cnt + 1 < maxw)
+				dst[cnt + 1] = (uint8_t) sym2;
+		}
+		cnt += two ? 2u : one ? 1u : 0u;
+		p += two ? l12 : one ? len : 0u;
 	}
-	return p;
+	return dead ? HEND : (p >= nbits && p < sub_end ? HEND : p);
 }
 
 #ifdef HUF_DEBUG
