@@ -80,7 +80,7 @@ struct Ctx {
 	hipStream_t user = nullptr;
 	bool use_user = false;
 	// scratch shared by both modes
-	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk;
+	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, hhint, hfin;
 	int use_v1 = -1; // PRESS_HIP_V1=1 selects the one-workgroup-per-read svb kernels (A/B)
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn;
@@ -258,11 +258,11 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 			h.lut32[i] = HUF_LONG | (e1 & 0xFFu);
 		} else {
 			const uint32_t s1 = e1 & 0xFFu, l1 = e1 >> 8;
-			uint32_t v = s1 | (l1 << 16) | (l1 << 20);
+			uint32_t v = s1 | (l1 << 16) | (l1 << 21) | (1u << 26);
 			const uint32_t rest = (uint32_t) HUF_LUT_BITS - l1;
 			const uint16_t e2 = h.lut[i >> l1]; // the upper bits are zeros, not stream bits:
 			if (e2 != 0xFFFFu && !(e2 & 0x8000u) && (uint32_t) (e2 >> 8) <= rest) // only a code that fits counts
-				v = s1 | ((uint32_t) (e2 & 0xFFu) << 8) | (l1 << 16) | ((l1 + (e2 >> 8)) << 20) | HUF_TWO;
+				v = s1 | ((uint32_t) (e2 & 0xFFu) << 8) | (l1 << 16) | ((l1 + (e2 >> 8)) << 21) | (2u << 26);
 			h.lut32[i] = v;
 		}
 	}
@@ -288,6 +288,20 @@ uint32_t max_chunks_of(uint64_t total_samples, uint32_t nreads)
 	return (uint32_t) (total_samples / CHUNK + nreads + 1);
 }
 
+// Huffman tiles of a batch (press_huffman.hip, k_huff_tiles): a read of n samples has at most
+// n - 1 codes of at most maxlen bits, cut into tiles of HUF_HT subsequences
+uint32_t max_htiles_of(uint64_t total_samples, uint32_t nreads)
+{
+	uint32_t minlen = 64, maxlen = 1;
+	for (int s = 0; s < 256; s++) {
+		minlen = g.tlen[s] < minlen ? g.tlen[s] : minlen;
+		maxlen = g.tlen[s] > maxlen ? g.tlen[s] : maxlen;
+	}
+	const uint64_t tb = (uint64_t) HUF_HT * (minlen >= 4 ? 128u : minlen >= 2 ? 64u : 32u);
+	const uint64_t mt = total_samples * maxlen / tb + nreads + 1;
+	return mt > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t) mt;
+}
+
 bool use_v1()
 {
 	if (g.use_v1 < 0) {
@@ -310,8 +324,12 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 	if (is_ex(method)) {
 		if (g.ex_pos.reserve((total_samples + 64) * 4) || g.ex_val.reserve((total_samples + 64) * 4))
 			return PRESS_HIP_EHIP;
-		if (decode && is_shuff(method) && g.low.reserve(total_samples + 64))
-			return PRESS_HIP_EHIP;
+		if (decode && is_shuff(method)) {
+			const size_t mt = max_htiles_of(total_samples, nreads);
+			if (g.low.reserve(total_samples + 64) || g.htiles.reserve(mt * sizeof(uint2)) ||
+			    g.hhint.reserve(mt * 4) || g.hfin.reserve(mt * 8))
+				return PRESS_HIP_EHIP;
+		}
 	}
 	return 0;
 }
@@ -427,7 +445,7 @@ extern "C" void press_hip_shutdown(void)
 		return;
 	(void) hipSetDevice(g.device);
 	(void) hipStreamSynchronize(g.own);
-	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.chunks, &g.gran, &g.ctl, &g.first_chunk, &g.sig, &g.off, &g.nsamp,
+	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.chunks, &g.gran, &g.ctl, &g.first_chunk, &g.htiles, &g.hhint, &g.hfin, &g.sig, &g.off, &g.nsamp,
 			  &g.arena, &g.arena_off, &g.lens, &g.lens2, &g.outn };
 	for (DevBuf *b : all)
 		b->release();
@@ -649,6 +667,18 @@ extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint
 	a.ctl = (ChunkCtl *) g.ctl.p;
 	a.first_chunk = (uint32_t *) g.first_chunk.p;
 	a.max_chunks = max_chunks_of(total_samples, nreads);
+	if (is_shuff(method)) {
+		a.htiles = (uint2 *) g.htiles.p;
+		a.hhint = (uint32_t *) g.hhint.p;
+		a.hfin = (uint64_t *) g.hfin.p;
+		a.max_htiles = max_htiles_of(total_samples, nreads);
+	}
+	if (is_shuff(method)) {
+		a.htiles = (uint2 *) g.htiles.p;
+		a.hhint = (uint32_t *) g.hhint.p;
+		a.hfin = (uint64_t *) g.hfin.p;
+		a.max_htiles = max_htiles_of(total_samples, nreads);
+	}
 
 	if (device_resident) {
 		if ((uintptr_t) sig & 15)

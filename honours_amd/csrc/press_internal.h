@@ -43,12 +43,17 @@ struct HuffDev {
 	uint16_t l2off[256];
 	uint8_t l2bits[256];
 	// two-symbol first level for the parallel decoder: sym1 | sym2 << 8 | len1 << 16 |
-	// (len1 + len2) << 20 | HUF_TWO when two whole codes fit in HUF_LUT_BITS bits;
-	// HUF_LONG | id for a long code's prefix; 0xFFFFFFFF: walk the trie
+	// (len1 + len2) << 21 | ncodes << 26, ncodes = 2 when two whole codes fit in HUF_LUT_BITS
+	// bits, else 1 (then the len1 + len2 field repeats len1); HUF_LONG | id for a long code's
+	// prefix; 0xFFFFFFFF: walk the trie
 	uint32_t lut32[1 << HUF_LUT_BITS];
 };
-constexpr uint32_t HUF_TWO = 1u << 28;
 constexpr uint32_t HUF_LONG = 1u << 30;
+
+// parallel Huffman decode (press_huffman.hip): tiles of HUF_HT subsequences, one workgroup each
+constexpr int HUF_HT = 512;     // threads per workgroup = subsequences per tile
+constexpr int HUF_HSYM = 32;    // most codes that can start in one subsequence
+constexpr uint32_t HUF_GRID = 512; // persistent workgroups (2 per CU: 78 KB of LDS each)
 
 // ---- chunked (v2) svb kernels: a read is cut into chunks of CHUNK samples, one workgroup
 // per chunk; chunks of a read are chained by a decoupled look-back over 8-byte granules.
@@ -115,6 +120,11 @@ struct DecodeArgs {
 	ChunkCtl *ctl;
 	uint32_t *first_chunk;    // [nreads] id of the first chunk of read r
 	uint32_t max_chunks;
+	// Huffman tiles (press_huffman.hip)
+	uint2 *htiles;            // [max_htiles] {read, tile index in the read | last << 31}
+	uint32_t *hhint;          // [max_htiles] speculative end position of a tile
+	uint64_t *hfin;           // [max_htiles] final {end position, symbols so far}
+	uint32_t max_htiles;
 };
 
 // Optional timing of the dominant kernel of a batch call with HIP events recorded on the
@@ -129,6 +139,7 @@ void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipSt
 void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_t s);
 void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, bool huff, hipStream_t s);
 void launch_ex_parse_huff(const DecodeArgs &a, int fmt, bool huff, hipStream_t s); // press_kernels.hip
+void launch_huff_decode(const DecodeArgs &a, hipStream_t s);                       // press_huffman.hip
 // pieces of the v1 pipeline reused by the chunked one (press_kernels.hip)
 void launch_ex_section(const BatchArgs &a, int fmt, bool huff, hipStream_t s);
 void launch_low_encode_huff_v1(const BatchArgs &a, hipStream_t s);

@@ -981,345 +981,6 @@ __global__ __launch_bounds__(64) void k_ex_parse(DecodeArgs a, int fmt, int huff
 	m->status = 0;
 }
 
-// ------------------------------------------------------------------ decode: static Huffman (huffman.c:1219)
-//
-// v1: one lane per read walks its bit stream with a 12-bit lookup table in LDS (codes of
-// the NA12878 table are 4..22 bits; longer-than-12 codes fall back to the trie).  The
-// reference stops when the input runs out (huffman.c:1246) and returns what it has.
-__global__ __launch_bounds__(64) void k_huff_decode(DecodeArgs a)
-{
-	__shared__ uint16_t lut[1 << HUF_LUT_BITS];
-	for (uint32_t i = threadIdx.x; i < (1u << HUF_LUT_BITS); i += 64)
-		lut[i] = a.huff->lut[i];
-	__syncthreads();
-
-	const uint32_t r = blockIdx.x * 64 + threadIdx.x;
-	if (r >= a.nreads)
-		return;
-	ReadMeta *m = a.meta + r;
-	if (m->status)
-		return;
-	const uint8_t *h = a.in + a.in_off[r] + m->hdr + m->seclen + 4;
-	const uint64_t nbytes = a.in_len[r] - m->hdr - m->seclen - 4;
-	const uint64_t nbits = nbytes * 8;
-	uint8_t *low = a.low + a.off[r];
-	const uint32_t want = m->nlow;
-
-	uint64_t acc = 0;    // bit window, next stream bit in bit 0
-	uint32_t have = 0;   // valid bits in acc
-	uint64_t nextb = 0;  // next byte to fetch
-	uint64_t used = 0;   // bits consumed
-	uint32_t got = 0;
-	while (got < want) {
-		while (have <= 56 && nextb < nbytes) {
-			acc |= (uint64_t) h[nextb++] << have;
-			have += 8;
-		}
-		uint32_t e = lut[(uint32_t) acc & ((1u << HUF_LUT_BITS) - 1u)];
-		uint32_t sym, len;
-		if (e < 0x8000u) {
-			sym = e & 0xFFu;
-			len = e >> 8;
-		} else {
-			int node = 0;
-			len = 0;
-			while (node >= 0 && a.huff->leaf[node] < 0 && len < 64) {
-				node = a.huff->child[node][(acc >> len) & 1u];
-				len++;
-			}
-			if (node < 0 || a.huff->leaf[node] < 0)
-				break; // no such code
-			sym = (uint32_t) a.huff->leaf[node];
-		}
-		if (used + len > nbits)
-			break; // the code runs off the end of the input
-		low[got++] = (uint8_t) sym;
-		acc >>= len;
-		have -= len;
-		used += len;
-	}
-	m->nlow = got;
-}
-
-// ------------------------------------------------------------------ decode: static Huffman, parallel
-//
-// The stream has no synchronisation points, but Huffman codes self-synchronise: a decoder
-// started at a wrong bit position falls back onto true code boundaries after a few codes.
-// One workgroup per read walks the bit stream in tiles of HT x S bits.  Thread i owns the
-// codes that START in its S-bit subsequence:
-//   pass 0   thread i decodes from the start of its subsequence (only thread 0's start -
-//            carried from the previous tile - is known to be a code boundary) and records
-//            where the first code of the next subsequence starts, E[i], and its count C[i];
-//   repeat   thread i takes E[i-1] as its start; if that differs from what it used before
-//            it decodes again; until no start changes (thread i is final after <= i
-//            rounds, in practice after 2-3; a code that never re-synchronises only costs
-//            rounds, never correctness);
-//   then     prefix sum of C -> output offsets, decode once more writing the symbols to
-//            LDS, flush with aligned 16-byte stores.
-// Result == huffman.c:1219 bit for bit, including its behaviour at the end of the input
-// (stops when the bytes run out or the symbol count is reached).
-
-constexpr int HT = 512;                 // threads per workgroup
-constexpr int HSYM = 32;                // most symbols a subsequence can hold (S = min(128, 32*minlen))
-constexpr uint32_t HEND = 0xFFFFFFFFu;  // "no further code": end of input or an undecodable prefix
-
-// decode the codes that start in [s, sub_end); returns where the next one starts.
-// lbits: LDS dwords of the tile, lbase = bit position of lbits[0]
-// LDS image of the tile's bits, transposed: dword j of the tile lives at LIDX(j), so that the
-// 64 lanes of a wave - whose read positions are one subsequence (D dwords) apart - hit
-// consecutive banks instead of every D-th one
-constexpr int HROW = 576;  // >= HT + a few, multiple of 64
-// D = dwords per subsequence = 1 << dsh
-__device__ __forceinline__ uint32_t lidx(uint32_t j, uint32_t dsh) { return (j & ((1u << dsh) - 1u)) * HROW + (j >> dsh); }
-
-// The loop is wave-uniform (it runs while any lane still has a code to decode) and
-// predicated rather than branched: lanes of a wave need different numbers of iterations, and
-// per-lane branches cost more scalar/exec bookkeeping than the few masked operations.
-template <bool WRITE>
-__device__ __forceinline__ uint32_t huff_sub(const uint32_t *lbits, uint32_t lbase, uint32_t D, const uint32_t *lut,
-					     const uint16_t *lut2, const uint16_t *l2off, const uint8_t *l2bits,
-					     const HuffDev *hd, uint32_t s, uint32_t sub_end, uint32_t nbits,
-					     uint32_t &cnt, uint8_t *dst, uint32_t maxw)
-{
-	uint32_t p = s;
-	cnt = 0;
-	const uint32_t lim = sub_end < nbits ? sub_end : nbits; // codes must START below this
-	bool dead = false;                                      // ran into the end / an undecodable prefix
-	for (;;) {
-		const bool act = !dead && p < lim;
-		if (!__any(act))
-			break;
-		const uint32_t lp = act ? p - lbase : 0u;
-		// 32 stream bits from position p (codes are at most 24 bits long)
-		const uint32_t wnd = __builtin_amdgcn_alignbit(lbits[lidx((lp >> 5) + 1, D)], lbits[lidx(lp >> 5, D)], lp & 31);
-		const uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
-		uint32_t sym = e & 0xFFu, sym2 = (e >> 8) & 0xFFu;
-		uint32_t len = (e >> 16) & 0xFu;
-		const uint32_t l12 = (e >> 20) & 0x1Fu;
-		bool ok = true;
-		if (__any(act && e >= HUF_LONG)) { // rare: a code longer than 12 bits somewhere in the wave
-			if (act && e >= HUF_LONG) {
-				if (e != 0xFFFFFFFFu) {
-					const uint32_t id = e & 0xFFu;
-					const uint32_t e2 = lut2[l2off[id] + ((wnd >> HUF_LUT_BITS) & ((1u << l2bits[id]) - 1u))];
-					ok = e2 != 0xFFFFu;
-					sym = e2 & 0xFFu;
-					len = e2 >> 8;
-				} else {
-					int node = 0;
-					len = 0;
-					while (node >= 0 && hd->leaf[node] < 0 && len < 32) {
-						node = hd->child[node][(wnd >> len) & 1u];
-						len++;
-					}
-					ok = node >= 0 && hd->leaf[node] >= 0;
-					sym = ok ? (uint32_t) hd->leaf[node] : 0u;
-				}
-			}
-		}
-		// two whole codes from one lookup when the second also starts in this subsequence
-		const bool two = act && e < HUF_LONG && (e & HUF_TWO) && p + len < lim && p + l12 <= nbits;
-		const bool one = act && !two && ok && p + len <= nbits;
-		if (act && !two && !one)
-			dead = true; // the code runs off the end of the input, or there is no such code
-		if (WRITE) {
-			if ((one || two) && cnt < maxw)
-				dst[cnt] = (uint8_t) sym;
-			if (two && cnt + 1 < maxw)
-				dst[cnt + 1] = (uint8_t) sym2;
-		}
-		cnt += two ? 2u : one ? 1u : 0u;
-		p += two ? l12 : one ? len : 0u;
-	}
-	return dead ? HEND : (p >= nbits && p < sub_end ? HEND : p);
-}
-
-#ifdef HUF_DEBUG
-__device__ unsigned long long g_hufdbg[8];
-extern "C" int press_hip_debug_huff(unsigned long long *dst)
-{
-	int rc = (int) hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_hufdbg), sizeof g_hufdbg);
-	unsigned long long z[8] = { 0 };
-	(void) hipMemcpyToSymbol(HIP_SYMBOL(g_hufdbg), z, sizeof z);
-	return rc;
-}
-#endif
-
-__global__ __launch_bounds__(HT) void k_huff_decode_par(DecodeArgs a)
-{
-	__shared__ uint32_t lut[1 << HUF_LUT_BITS];
-	__shared__ uint16_t lut2[HUF_L2_ENTRIES];
-	__shared__ uint16_t l2off[256];
-	__shared__ uint8_t l2bits[256];
-	__shared__ __attribute__((aligned(16))) uint32_t lbits[4 * HROW];
-	__shared__ uint32_t sE[HT];
-	__shared__ uint32_t sC[HT];
-	__shared__ uint32_t wtot[HT / 64];
-	__shared__ __attribute__((aligned(16))) uint8_t obuf[16 + HT * HSYM + 16];
-
-	const uint32_t r = blockIdx.x;
-	ReadMeta *m = a.meta + r;
-	if (m->status)
-		return;
-	for (uint32_t i = threadIdx.x; i < (1u << HUF_LUT_BITS); i += HT)
-		lut[i] = a.huff->lut32[i];
-	for (uint32_t i = threadIdx.x; i < (uint32_t) HUF_L2_ENTRIES; i += HT)
-		lut2[i] = a.huff->lut2[i];
-	if (threadIdx.x < 256) {
-		l2off[threadIdx.x] = a.huff->l2off[threadIdx.x];
-		l2bits[threadIdx.x] = a.huff->l2bits[threadIdx.x];
-	}
-	const uint32_t hdr = m->hdr + m->seclen + 4;
-	const uint8_t *h = a.in + a.in_off[r] + hdr;
-	const uint64_t nbytes64 = a.in_len[r] - hdr;
-	const uint32_t nbytes = nbytes64 > 0x1FFFFFFFull ? 0x1FFFFFFFu : (uint32_t) nbytes64;
-	const uint32_t nbits = nbytes * 8;
-	const uint32_t want = m->nlow;
-	uint8_t *low = a.low + a.off[r];
-	const uint32_t minlen = a.huff->minlen;
-	// bits per subsequence: at most HSYM = 32 codes start in one, and it is >= the longest code (24)
-	// (1024 threads x 64-bit subsequences was measured 1.7x slower than 512 x 128)
-	const uint32_t D = minlen >= 4 ? 2u : minlen >= 2 ? 1u : 0u; // log2(dwords per subsequence)
-	const uint32_t S = 32u << D;
-	const uint32_t tid = threadIdx.x;
-
-	// output FIFO state (see fifo_flush): obuf[0] <-> global address g (16-byte aligned)
-	uint32_t skip = (uint32_t) ((uintptr_t) low & 15);
-	uint8_t *g = low - skip;
-	uint32_t fill = skip;
-
-	uint32_t pos = 0; // bit position of the next tile = a true code boundary
-	uint32_t got = 0;
-	__syncthreads();
-	while (got < want && pos < nbits) {
-		// ---- stage the tile's bits: lbits[j] = payload bytes [4*(pos/32 + j), +4)
-		const uint32_t base_dw = pos >> 5;
-		const uint32_t lbase = base_dw << 5;
-		const uint32_t ndw = (HT * S) / 32 + 4;
-		for (uint32_t j = tid; j < ndw; j += HT) {
-			const uint64_t b = 4ull * (base_dw + j);
-			uint32_t v = 0;
-			if (b + 4 <= nbytes) {
-				__builtin_memcpy(&v, h + b, 4);
-			} else {
-				for (uint32_t q = 0; q < 4; q++)
-					if (b + q < nbytes)
-						v |= (uint32_t) h[b + q] << (8 * q);
-			}
-			lbits[lidx(j, D)] = v;
-		}
-		__syncthreads();
-
-#ifdef HUF_DEBUG
-		if (tid == 0)
-			atomicAdd(&g_hufdbg[0], 1ull); // tiles
-#endif
-		// ---- pass 0 and the synchronisation rounds
-		const uint32_t sub0 = pos + tid * S;
-		const uint32_t sub_end = sub0 + S;
-		uint32_t start = sub0;
-		uint32_t cnt;
-		uint32_t e = huff_sub<false>(lbits, lbase, D, lut, lut2, l2off, l2bits, a.huff, start, sub_end, nbits, cnt, nullptr, 0);
-		sE[tid] = e;
-		sC[tid] = cnt;
-		for (;;) {
-			__syncthreads();
-			int changed = 0;
-			const uint32_t ns = tid ? sE[tid - 1] : pos;
-			if (ns != start) {
-				start = ns;
-				changed = 1;
-			}
-			if (__syncthreads_or(changed) == 0)
-				break;
-#ifdef HUF_DEBUG
-			if (tid == 0)
-				atomicAdd(&g_hufdbg[1], 1ull); // rounds
-			if (changed)
-				atomicAdd(&g_hufdbg[2], 1ull); // re-decodes
-#endif
-			if (changed) {
-				if (start == HEND) {
-					e = HEND;
-					cnt = 0;
-				} else {
-					e = huff_sub<false>(lbits, lbase, D, lut, lut2, l2off, l2bits, a.huff, start, sub_end, nbits, cnt, nullptr, 0);
-				}
-				sE[tid] = e;
-				sC[tid] = cnt;
-			}
-		}
-
-		// ---- offsets: exclusive prefix of the counts over the workgroup
-		uint32_t inc = cnt;
-		{
-			const int lane = tid & 63;
-#pragma unroll
-			for (int dd = 1; dd < 64; dd <<= 1) {
-				const uint32_t t2 = __shfl_up(inc, dd, 64);
-				if (lane >= dd)
-					inc += t2;
-			}
-			if (lane == 63)
-				wtot[tid >> 6] = inc;
-		}
-		__syncthreads();
-		uint32_t base = 0, total = 0;
-#pragma unroll
-		for (int w2 = 0; w2 < HT / 64; w2++) {
-			const uint32_t x = wtot[w2];
-			if (w2 < (int) (tid >> 6))
-				base += x;
-			total += x;
-		}
-		const uint32_t excl = base + inc - cnt;
-		const uint32_t room = want - got;                 // symbols still wanted
-		const uint32_t take = total < room ? total : room; // symbols this tile delivers
-		const uint32_t maxw = excl < take ? take - excl : 0u;
-		// ---- final pass: symbols into the LDS FIFO
-		if (cnt && maxw && start != HEND) {
-			uint32_t c2;
-			(void) huff_sub<true>(lbits, lbase, D, lut, lut2, l2off, l2bits, a.huff, start, sub_end, nbits, c2, obuf + fill + excl, maxw);
-		}
-		const uint32_t last_e = sE[HT - 1];
-		__syncthreads();
-		// flush whole 16-byte chunks, keep the rest for the next tile
-		{
-			const uint32_t tot = fill + take;
-			const uint32_t nch = tot >> 4;
-			for (uint32_t c = tid; c < nch; c += HT) {
-				const uint4 v = reinterpret_cast<const uint4 *>(obuf)[c];
-				if (c == 0 && skip) {
-					const uint32_t wv[4] = { v.x, v.y, v.z, v.w };
-					for (uint32_t b = skip; b < 16; b++)
-						g[b] = (uint8_t) (wv[b >> 2] >> (8 * (b & 3)));
-				} else {
-					reinterpret_cast<uint4 *>(g)[c] = v;
-				}
-			}
-			if (nch) {
-				if (tid == 0) {
-					const uint4 tl = reinterpret_cast<const uint4 *>(obuf)[nch];
-					reinterpret_cast<uint4 *>(obuf)[0] = tl;
-				}
-				skip = 0;
-			}
-			g += (size_t) nch * 16;
-			fill = tot & 15;
-		}
-		got += take;
-		if (last_e == HEND || take < total)
-			break;
-		pos = last_e;
-		__syncthreads();
-	}
-	__syncthreads();
-	for (uint32_t b = skip + tid; b < fill; b += HT)
-		g[b] = obuf[b];
-	if (tid == 0)
-		m->nlow = got;
-}
-
 // ------------------------------------------------------------------ decode: merge + undo zig-zag delta
 //
 // Second half of vbe21_depress (press.c:2757-2771) fused with unzigdelta_u16_16
@@ -1486,32 +1147,21 @@ void launch_ex_encode(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
 // dominant kernel of those methods)
 void launch_ex_parse_huff(const DecodeArgs &a, int fmt, bool huff, hipStream_t s)
 {
-	const bool huff_parallel = getenv("PRESS_HIP_HUFF_SERIAL") == nullptr;
 	hipLaunchKernelGGL(k_ex_parse, dim3(a.nreads), dim3(64), 0, s, a, fmt, huff ? 1 : 0);
 	if (huff) {
 		ktime_begin(1, s);
-		if (huff_parallel)
-			hipLaunchKernelGGL(k_huff_decode_par, dim3(a.nreads), dim3(HT), 0, s, a);
-		else
-			hipLaunchKernelGGL(k_huff_decode, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a);
+		launch_huff_decode(a, s);
 		ktime_end(1, s);
 	}
 }
 
 void launch_ex_decode(const DecodeArgs &a, int fmt, bool huff, hipStream_t s)
 {
-	const bool huff_parallel = getenv("PRESS_HIP_HUFF_SERIAL") == nullptr;
 	if (!a.nreads)
 		return;
 	const dim3 grid(a.nreads);
-	hipLaunchKernelGGL(k_ex_parse, grid, dim3(64), 0, s, a, fmt, huff ? 1 : 0);
+	launch_ex_parse_huff(a, fmt, huff, s);
 	if (huff) {
-		ktime_begin(1, s);
-		if (huff_parallel)
-			hipLaunchKernelGGL(k_huff_decode_par, grid, dim3(HT), 0, s, a);
-		else // codes longer than a subsequence could hold: one lane per read
-			hipLaunchKernelGGL(k_huff_decode, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a);
-		ktime_end(1, s);
 		hipLaunchKernelGGL((k_low_decode<true>), grid, dim3(WG), 0, s, a);
 	} else {
 		ktime_begin(1, s);
