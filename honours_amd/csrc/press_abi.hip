@@ -80,7 +80,7 @@ struct Ctx {
 	hipStream_t user = nullptr;
 	bool use_user = false;
 	// scratch shared by both modes
-	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, hhint, hfin;
+	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, hgran;
 	int use_v1 = -1; // PRESS_HIP_V1=1 selects the one-workgroup-per-read svb kernels (A/B)
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn;
@@ -222,7 +222,7 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 			if (len[s] <= (uint32_t) HUF_LUT_BITS)
 				continue;
 			const int pfx = (int) (bits[s] & ((1u << HUF_LUT_BITS) - 1));
-			if (id_of[pfx] < 0 && nid < 256) {
+			if (id_of[pfx] < 0 && nid < HUF_L2_IDS) {
 				prefix_of[nid] = pfx;
 				id_of[pfx] = nid++;
 			}
@@ -326,8 +326,8 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 			return PRESS_HIP_EHIP;
 		if (decode && is_shuff(method)) {
 			const size_t mt = max_htiles_of(total_samples, nreads);
-			if (g.low.reserve(total_samples + 64) || g.htiles.reserve(mt * sizeof(uint2)) ||
-			    g.hhint.reserve(mt * 4) || g.hfin.reserve(mt * 8))
+			if (g.low.reserve(total_samples + 64) || g.htiles.reserve(mt * sizeof(HufTile)) ||
+			    g.hgran.reserve(mt * 8))
 				return PRESS_HIP_EHIP;
 		}
 	}
@@ -445,7 +445,7 @@ extern "C" void press_hip_shutdown(void)
 		return;
 	(void) hipSetDevice(g.device);
 	(void) hipStreamSynchronize(g.own);
-	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.chunks, &g.gran, &g.ctl, &g.first_chunk, &g.htiles, &g.hhint, &g.hfin, &g.sig, &g.off, &g.nsamp,
+	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.chunks, &g.gran, &g.ctl, &g.first_chunk, &g.htiles, &g.hgran, &g.sig, &g.off, &g.nsamp,
 			  &g.arena, &g.arena_off, &g.lens, &g.lens2, &g.outn };
 	for (DevBuf *b : all)
 		b->release();
@@ -668,15 +668,13 @@ extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint
 	a.first_chunk = (uint32_t *) g.first_chunk.p;
 	a.max_chunks = max_chunks_of(total_samples, nreads);
 	if (is_shuff(method)) {
-		a.htiles = (uint2 *) g.htiles.p;
-		a.hhint = (uint32_t *) g.hhint.p;
-		a.hfin = (uint64_t *) g.hfin.p;
+		a.htiles = (HufTile *) g.htiles.p;
+		a.hgran = (uint64_t *) g.hgran.p;
 		a.max_htiles = max_htiles_of(total_samples, nreads);
 	}
 	if (is_shuff(method)) {
-		a.htiles = (uint2 *) g.htiles.p;
-		a.hhint = (uint32_t *) g.hhint.p;
-		a.hfin = (uint64_t *) g.hfin.p;
+		a.htiles = (HufTile *) g.htiles.p;
+		a.hgran = (uint64_t *) g.hgran.p;
 		a.max_htiles = max_htiles_of(total_samples, nreads);
 	}
 

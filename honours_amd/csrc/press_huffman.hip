@@ -4,26 +4,33 @@
 // started at a wrong bit position falls back onto true code boundaries after a few codes.
 // The payload of every read is cut into TILES of HT subsequences of S bits (S = 128 for
 // the NA12878 table); one 512-thread workgroup per tile, handed out in ticket order by a
-// persistent grid that keeps the lookup tables in LDS.  Thread i owns the codes that
-// START in subsequence i:
-//   pass 0    every thread decodes from the first bit of its subsequence and records where
-//             the first code of the next subsequence starts, E[i];
-//   rounds    thread i takes E[i-1] as its start; whoever's start changed decodes again -
-//             the changed threads are compacted so that a round with few changes costs a
-//             few waves, not eight - until nothing changes (thread i is final after <= i
-//             rounds; in practice after 2-3).  These passes write their symbols into a
-//             private 36-byte LDS slot per thread;
-//   chain     tiles of one read are chained twice.  As soon as a tile has converged under
-//             the assumption that its first bit starts a code, it publishes where its last
-//             code ends as a HINT; its successor re-converges from that hint (one or two
-//             lanes decode again) without waiting for anything else.  The FINAL granule -
-//             {true end position, symbols up to and including this tile} - travels down the
-//             read behind that: a tile waits for its predecessor's FINAL, checks that the
-//             end position is the hint it used (if not it converges once more), and
-//             publishes its own.  The wait therefore costs one L2 round trip per tile, and
-//             a wrong hint only costs time.  Ticket order makes the waits deadlock free:
-//             a predecessor was always taken by a workgroup that is already running;
-//   output    prefix sum of the counts, slots -> contiguous LDS image -> 16-byte stores.
+// persistent grid that keeps the lookup tables in LDS (53 KB per workgroup: 3 per CU).
+// Thread i owns the codes that START in subsequence i:
+//   pass 0     thread i decodes subsequence i-1 from its first bit (thread 0: the last
+//              subsequence of the previous tile) and records where the first code of
+//              subsequence i starts, E[i-1];
+//   rounds     thread i takes E[i-1] as its start; whoever's start changed decodes again -
+//              the changed threads are compacted so that a round with few changes costs a
+//              wave, not eight - until nothing changes (thread i is final after <= i rounds;
+//              in practice after 2-3).  These passes leave their symbols in a private
+//              36-byte LDS slot per thread;
+//   look-back  a tile other than a read's first does not know where its first code starts.
+//              It converges from what pass 0 found across the tile boundary (right in ~97 %
+//              of the tiles), then publishes an AGGREGATE granule
+//              {start it assumed, where its last code ends, codes it holds}.  The end of
+//              the predecessor's granule is the tile's real start: if it differs from the
+//              assumption the tile converges again from there (one or two lanes decode) and
+//              publishes the new aggregate.  A granule whose assumed start is the true start
+//              carries true values, whenever it was read; so a tile walks back over its
+//              predecessors' granules - 64 per round trip - checking that each one's
+//              assumed start equals the end of the one before it, down to a PREFIX granule
+//              {true end, codes up to and including that tile} (a read's first tile always
+//              publishes one).  The sum is its output offset, and it publishes a prefix
+//              itself.  No tile waits for another tile's look-back; ticket order makes the
+//              waits deadlock free (a predecessor was always taken by a workgroup that is
+//              already running), and a wrong assumption only costs time;
+//   output     prefix sum of the counts, then every thread copies its slot to the one-byte
+//              stream with (unaligned) 4-byte stores.
 // Result == huffman.c:1219 bit for bit, including its behaviour at the end of the input
 // (stops when the bytes run out or the symbol count is reached; a code cut off by the end
 // of the input is not delivered).
@@ -32,14 +39,16 @@
 
 namespace ph {
 
-constexpr uint32_t HEND = 0xFFFFFFFFu;  // "no further code": end of input or an undecodable prefix
-constexpr uint32_t HNONE = 0xFFFFFFFEu; // never a start position: forces the first round to decode everybody
-constexpr int HSLOT = 36;               // bytes per private symbol slot: HSYM + spill; 9 dwords = bank-conflict-free stride
-constexpr int HLB_DW = 2176;            // LDS dwords of the bit image (2048 + reach of the last code, skewed)
-constexpr uint32_t HINT_READY = 1u << 31;
-constexpr uint32_t HINT_END = 1u << 30;
-constexpr uint64_t FIN_READY = 1ull << 63;
-constexpr uint64_t FIN_END = 1ull << 62;
+constexpr uint32_t HEND = 0xFFFFFFFFu; // "no further code": end of input or an undecodable prefix
+constexpr int HSLOT = 36;              // bytes per private symbol slot: HSYM + spill; 9 dwords = bank-conflict-free stride
+constexpr int HLB_DW = 2096;           // LDS dwords of the bit image (one subsequence before the tile + 2048 + reach of the last code, skewed)
+// packed per-thread result: position (20 bits) | END << 20 | codes << 24
+constexpr uint32_t PE_END = 1u << 20;
+constexpr uint32_t ST_NONE = 0xFFu, ST_END = 0xFEu; // sS: start relative to the subsequence, or these
+// look-back granules: state << 62 | assumed start << 56 | end << 48 | codes; positions are
+// relative to the tile boundary (0..23), 63 = the stream has ended
+constexpr uint64_t GR_AGG = 1ull << 62, GR_PFX = 2ull << 62;
+constexpr uint32_t GP_END = 63;
 
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
 
@@ -51,6 +60,8 @@ __device__ __forceinline__ uint32_t la(uint32_t j) { return j + (j >> 6); }
 // Decode the codes that start in [start, sub_end) of the tile (bit positions relative to
 // the tile); returns where the next code starts, or HEND.  nbits = end of the payload.
 // WRITE: symbols go to `slot`, their number to `cnt`.
+// The lane keeps a 64-bit window {hi, lo} of the stream in registers and fetches the dword
+// after it while the table lookup is in flight, so a step costs one LDS round trip.
 template <bool WRITE>
 __device__ __forceinline__ uint32_t huff_run(const uint32_t *lbits, const uint32_t *lut, const uint16_t *lut2,
 					     const uint16_t *l2off, const uint8_t *l2bits, const HuffDev *hd,
@@ -62,6 +73,8 @@ __device__ __forceinline__ uint32_t huff_run(const uint32_t *lbits, const uint32
 	if (bad)
 		lim = 0;
 	uint32_t c = 0;
+	uint32_t j = p >> 5;
+	uint32_t lo = lbits[la(j)], hi = lbits[la(j) + 1];
 	// wave-uniform and predicated: lanes need different numbers of steps, and per-lane
 	// branches cost more than the few masked operations
 	for (;;) {
@@ -69,15 +82,15 @@ __device__ __forceinline__ uint32_t huff_run(const uint32_t *lbits, const uint32
 		if (!__any(act))
 			break;
 		if (act) {
-			const uint32_t ad = (p >> 5) + (p >> 11);
+			const uint32_t nxt = lbits[la(j + 2)];
 			// 32 stream bits from position p (codes are at most 24 bits long)
-			const uint32_t wnd = __builtin_amdgcn_alignbit(lbits[ad + 1], lbits[ad], p & 31);
+			const uint32_t wnd = __builtin_amdgcn_alignbit(hi, lo, p & 31);
 			uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
 			if (e >= HUF_LONG) { // rare: a code longer than 12 bits
 				uint32_t sym = 0, len = 0;
 				bool ok;
-				if (e != 0xFFFFFFFFu) {
-					const uint32_t id = e & 0xFFu;
+				const uint32_t id = e & 0xFFu;
+				if (e != 0xFFFFFFFFu && id < (uint32_t) HUF_L2_IDS) {
 					const uint32_t e2 = lut2[l2off[id] + ((wnd >> HUF_LUT_BITS) & ((1u << l2bits[id]) - 1u))];
 					ok = e2 != 0xFFFFu;
 					sym = e2 & 0xFFu;
@@ -109,6 +122,12 @@ __device__ __forceinline__ uint32_t huff_run(const uint32_t *lbits, const uint32
 				c += both ? n2 : (n2 ? 1u : 0u);
 			}
 			p += both ? ((e >> 21) & 0x1Fu) : len1;
+			const uint32_t jn = p >> 5; // a step crosses at most one dword
+			if (jn != j) {
+				lo = hi;
+				hi = nxt;
+			}
+			j = jn;
 		}
 	}
 	if (!bad && p > nbits) { // the last code ran off the end of the input: not delivered
@@ -119,19 +138,71 @@ __device__ __forceinline__ uint32_t huff_run(const uint32_t *lbits, const uint32
 	return bad ? HEND : (p >= nbits && p < sub_end ? HEND : p);
 }
 
-__device__ __forceinline__ uint32_t poll32(uint32_t *p)
+__device__ __forceinline__ uint64_t gran_ld(uint64_t *g)
 {
-	uint32_t v;
-	while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0)
-		__builtin_amdgcn_s_sleep(2);
+	return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gran_st(uint64_t *g, uint64_t v)
+{
+	__hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v)
+{
+#pragma unroll
+	for (int dd = 32; dd >= 1; dd >>= 1) {
+		const uint32_t lo = (uint32_t) __shfl_xor((int) (uint32_t) v, dd, 64);
+		const uint32_t hi = (uint32_t) __shfl_xor((int) (uint32_t) (v >> 32), dd, 64);
+		v += ((uint64_t) hi << 32) | lo;
+	}
 	return v;
 }
-__device__ __forceinline__ uint64_t poll64(uint64_t *p)
+
+// Look-back of tile k (index t >= 1 in its read), executed by one wave.  my_s = the start
+// this tile's current result assumed.  Returns LB_DONE | codes in front of the tile once
+// the chain of aggregates is validated down to a prefix, or the predecessor's end position
+// (0..23, GP_END) if that is not my_s: the tile has to converge again from there.
+constexpr uint64_t LB_DONE = 1ull << 63;
+__device__ __forceinline__ uint64_t tile_lookback(uint64_t *gran, uint32_t k, uint32_t t, uint32_t my_s)
 {
-	uint64_t v;
-	while ((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0)
-		__builtin_amdgcn_s_sleep(2);
-	return v;
+	const uint32_t lane = threadIdx.x & 63;
+	for (;;) {
+		uint64_t sum = 0;
+		uint32_t need = my_s; // the end position the next (farther) granule must show
+		uint32_t done = 0;    // predecessors already validated
+		for (;;) {
+			const uint32_t idx = done + lane; // lane l looks at tile k - 1 - idx
+			const bool have = idx < t;
+			uint64_t g = 0;
+			if (have)
+				g = gran_ld(gran + (k - 1 - idx));
+			const uint32_t st = (uint32_t) (g >> 62);
+			const uint32_t gs = (uint32_t) (g >> 56) & 63u;
+			const uint32_t ge = (uint32_t) (g >> 48) & 63u;
+			uint32_t prev_s = (uint32_t) __shfl_up((int) gs, 1, 64);
+			if (lane == 0)
+				prev_s = need;
+			const bool pub = have && st != 0;
+			const bool linkok = pub && ge == prev_s;
+			const unsigned long long badm = __ballot(have && !linkok);
+			const unsigned long long pfxm = __ballot(linkok && st == 2);
+			const uint32_t fb = badm ? (uint32_t) __builtin_ctzll(badm) : 64u;
+			const uint32_t fp = pfxm ? (uint32_t) __builtin_ctzll(pfxm) : 64u;
+			if (fp < fb) // validated down to a prefix
+				return LB_DONE | (sum + wave_sum64(lane <= fp ? (g & 0xFFFFFFFFull) : 0ull));
+			if (fb < 64) {
+				const uint32_t pub0 = (uint32_t) __shfl((int) (pub ? 1 : 0), 0, 64);
+				const uint32_t ge0 = (uint32_t) __shfl((int) ge, 0, 64);
+				if (fb == 0 && done == 0 && pub0)
+					return ge0; // the predecessor ends somewhere else than assumed
+				break;              // not published yet / being corrected by its owner: poll again
+			}
+			// 64 consistent aggregates and no prefix among them: keep walking
+			sum += wave_sum64(g & 0xFFFFFFFFull);
+			need = (uint32_t) __shfl((int) gs, 63, 64);
+			done += 64;
+		}
+		__builtin_amdgcn_s_sleep(4);
+	}
 }
 
 #ifdef HUF_DEBUG
@@ -143,44 +214,46 @@ extern "C" int press_hip_debug_huff(unsigned long long *dst)
 	(void) hipMemcpyToSymbol(HIP_SYMBOL(g_hufdbg), z, sizeof z);
 	return rc;
 }
-#define HSTAMP(i) do { if (tid == 0) { const unsigned long long now_ = clock64(); atomicAdd(&g_hufdbg[i], now_ - stamp_); stamp_ = now_; } } while (0)
-#define HCOUNT(i, v) do { if (tid == 0) atomicAdd(&g_hufdbg[i], (unsigned long long) (v)); } while (0)
+// per-workgroup accumulation in registers, one atomicAdd per counter when the workgroup exits
+#define HSTAMP(i) do { const unsigned long long now_ = clock64(); acc_[i] += now_ - stamp_; stamp_ = now_; } while (0)
+#define HCOUNT(i, v) do { acc_[i] += (unsigned long long) (v); } while (0)
 #else
 #define HSTAMP(i) do { } while (0)
 #define HCOUNT(i, v) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(HUF_HT) void k_huff_decode_tiles(DecodeArgs a)
+__global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) // 6 waves per SIMD = 3 workgroups per CU
 {
 #ifdef HUF_DEBUG
 	unsigned long long stamp_ = clock64();
+	unsigned long long acc_[12] = { 0 };
 #endif
 	constexpr int HT = HUF_HT;
 	__shared__ uint32_t lut[1 << HUF_LUT_BITS];
 	__shared__ uint16_t lut2[HUF_L2_ENTRIES];
-	__shared__ uint16_t l2off[256];
-	__shared__ uint8_t l2bits[256];
+	__shared__ uint16_t l2off[HUF_L2_IDS];
+	__shared__ uint8_t l2bits[HUF_L2_IDS];
 	__shared__ uint32_t lbits[HLB_DW];
-	__shared__ uint32_t sS[HT];      // start position each thread's current result was decoded from
-	__shared__ uint32_t sE[HT];      // ... where the code after its subsequence starts
-	__shared__ uint32_t sC[HT];      // ... how many codes start in its subsequence
-	__shared__ uint16_t lst_id[HT];  // compacted list of threads whose start changed
-	__shared__ uint32_t lst_start[HT];
+	__shared__ uint32_t sE[HT + 1]; // sE[i]: where the first code of image subsequence i+1... see below
+	__shared__ uint8_t sS[HT];      // the start (relative to its subsequence) thread i's result was decoded from
+	__shared__ uint16_t lst[HT];    // compacted list of threads whose start changed: id | start << 9 | END << 14
 	__shared__ uint32_t lst_n[2];
 	__shared__ uint32_t wtot[HT / 64];
 	__shared__ uint32_t s_ticket;
-	__shared__ uint32_t s_hint;
-	__shared__ uint64_t s_fin;
+	__shared__ uint64_t s_res;
 	__shared__ __attribute__((aligned(16))) uint8_t slots[HT * HSLOT];
-	__shared__ __attribute__((aligned(16))) uint8_t obuf[16 + HT * HUF_HSYM + 16];
 
+	// Positions inside the kernel are relative to the LDS image, which starts one subsequence
+	// before the tile: image subsequence 0 is the previous tile's last one, thread i owns image
+	// subsequence i+1.  sE[i] = where the first code at or after the start of image subsequence
+	// i+1 begins (| PE_END), and for i >= 1 | (codes of thread i-1) << 24.
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
 	for (uint32_t i = tid; i < (1u << HUF_LUT_BITS); i += HT)
 		lut[i] = a.huff->lut32[i];
 	for (uint32_t i = tid; i < (uint32_t) HUF_L2_ENTRIES; i += HT)
 		lut2[i] = a.huff->lut2[i];
-	if (tid < 256) {
+	if (tid < (uint32_t) HUF_L2_IDS) {
 		l2off[tid] = a.huff->l2off[tid];
 		l2bits[tid] = a.huff->l2bits[tid];
 	}
@@ -190,21 +263,21 @@ __global__ __launch_bounds__(HUF_HT) void k_huff_decode_tiles(DecodeArgs a)
 	const uint32_t TB = HT * S;
 	const uint32_t nalloc = uniform(a.ctl->nchunks);
 	const uint32_t ntiles = nalloc < a.max_htiles ? nalloc : a.max_htiles;
-	const uint32_t sub0 = tid * S;
-	uint8_t *const myslot = slots + tid * HSLOT;
-	uint32_t round = 0; // parity selects lst_n
+	const uint32_t ndw = (TB + S) / 32 + 4; // dwords of the image
+	uint32_t round = 0;                     // parity selects lst_n
 
 	// converge: repeat "take the left neighbour's end as start, decode again if it changed"
-	// until nothing changes; pos0 = start of thread 0.  Barriers inside; all threads call it.
-	auto converge = [&](uint32_t pos0, uint32_t nbits) {
+	// until nothing changes.  Barriers inside; all threads call it.
+	auto converge = [&](uint32_t nbits) {
 		for (;;) {
 			const uint32_t par = round & 1u;
 			round++;
 			if (tid == 0)
 				lst_n[par] = 0;
 			__syncthreads();
-			const uint32_t ns = tid ? sE[tid - 1] : pos0;
-			const bool ch = ns != sS[tid];
+			const uint32_t pe = sE[tid];
+			const uint32_t code = (pe & PE_END) ? ST_END : ((pe & 0xFFFFFu) - (tid + 1) * S);
+			const bool ch = code != sS[tid];
 			const unsigned long long m = __ballot(ch);
 			uint32_t base = 0;
 			if (lane == 0 && m)
@@ -212,8 +285,7 @@ __global__ __launch_bounds__(HUF_HT) void k_huff_decode_tiles(DecodeArgs a)
 			base = (uint32_t) __shfl((int) base, 0, 64);
 			if (ch) {
 				const uint32_t idx = base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
-				lst_id[idx] = (uint16_t) tid;
-				lst_start[idx] = ns;
+				lst[idx] = (uint16_t) (tid | ((code & 31u) << 9) | ((pe & PE_END) ? (1u << 14) : 0u));
 			}
 			__syncthreads();
 			const uint32_t nch = lst_n[par];
@@ -223,107 +295,96 @@ __global__ __launch_bounds__(HUF_HT) void k_huff_decode_tiles(DecodeArgs a)
 			HCOUNT(11, nch);
 			if ((tid & ~63u) < nch) { // whole waves beyond the list skip
 				const bool mine = tid < nch;
-				const uint32_t u = mine ? lst_id[tid] : 0u;
-				const uint32_t st = mine ? lst_start[tid] : HEND;
+				const uint32_t ent = mine ? lst[tid] : (1u << 14);
+				const uint32_t u = ent & 511u;
+				const bool end = (ent >> 14) & 1u;
+				const uint32_t rel = (ent >> 9) & 31u;
 				uint32_t c;
-				const uint32_t e = huff_run<true>(lbits, lut, lut2, l2off, l2bits, a.huff, st, (u + 1) * S, nbits, c,
-								  mine ? slots + u * HSLOT : slots);
+				const uint32_t e = huff_run<true>(lbits, lut, lut2, l2off, l2bits, a.huff,
+								  end ? HEND : (u + 1) * S + rel, (u + 2) * S, nbits, c, slots + u * HSLOT);
 				if (mine) {
-					sS[u] = st;
-					sE[u] = e;
-					sC[u] = c;
+					sS[u] = (uint8_t) (end ? ST_END : rel);
+					sE[u + 1] = (e == HEND ? PE_END : e) | (c << 24);
 				}
 			}
 		}
 	};
 
+	// loads of a tile's image dwords tid + q * HT (zeros outside the payload)
+	auto load_bits = [&](const HufTile &d, uint32_t v[5]) {
+		const uint8_t *src = a.in + d.src;
+		const int64_t nby = (int64_t) (d.nbits >> 3); // payload bytes from the tile start on
+		const bool first = (d.t_last & 0x7FFFFFFFu) == 0;
+#pragma unroll
+		for (int q = 0; q < 5; q++) {
+			const uint32_t j = tid + q * HT;
+			const int64_t rb = 4ll * j - (int64_t) (S >> 3); // byte offset from the tile start
+			v[q] = 0;
+			if (j < ndw && (rb >= 0 || !first) && rb + 4 <= nby)
+				__builtin_memcpy(&v[q], src + rb, 4);
+		}
+	};
+
 	for (;;) {
-		__syncthreads(); // tables loaded / previous tile's LDS no longer in use
 		if (tid == 0)
 			s_ticket = atomicAdd(&a.ctl->ticket, 1u);
 		__syncthreads();
 		const uint32_t k = s_ticket;
 		if (k >= ntiles)
 			break;
+		const HufTile d = a.htiles[k];
+		uint32_t v[5];
+		load_bits(d, v);
 		HSTAMP(0); // ticket
 		HCOUNT(8, 1);
-		const uint2 desc = a.htiles[k];
-		const uint32_t r = uniform(desc.x);
-		const uint32_t t = uniform(desc.y) & 0x7FFFFFFFu;
-		const bool last = (uniform(desc.y) >> 31) != 0; // no tile of this read follows
-		const ReadMeta *m = a.meta + r;
-		const uint32_t hdr = uniform(m->hdr) + uniform(m->seclen) + 4;
-		const uint8_t *h = a.in + a.in_off[r] + hdr;
-		const uint64_t nbytes64 = a.in_len[r] - hdr;
-		const uint32_t nbytes = uniform(nbytes64 > 0x1FFFFFFFull ? 0x1FFFFFFFu : (uint32_t) nbytes64);
-		const uint32_t want = uniform(m->nlow);
-		const uint32_t tile_bit0 = t * TB;                // < 8 * nbytes by construction (k_huff_tiles)
-		const uint32_t nbits = nbytes * 8 - tile_bit0;    // payload end, relative to the tile
-		uint8_t *low = a.low + a.off[r];
+		const uint32_t t = uniform(d.t_last) & 0x7FFFFFFFu;
+		const bool last = (uniform(d.t_last) >> 31) != 0; // no tile of this read follows
+		const uint32_t r = uniform(d.read);
+		const uint32_t want = uniform(d.want);
+		const uint32_t nbits = uniform(d.nbits) + S; // payload end in image coordinates
+		uint8_t *low = a.low + d.low;
 
-		// ---- stage the tile's bits: lbits[la(j)] = payload bytes [4*(tile_dw0 + j), +4), zeros past the end
+		// ---- stage the tile's bits: lbits[la(j)] = image dword j
 		{
-			const uint32_t dw0 = tile_bit0 >> 5;
-			const uint32_t ndw = TB / 32 + 4;
-			for (uint32_t j = tid; j < ndw; j += HT) {
-				const uint64_t b = 4ull * (dw0 + j);
-				uint32_t v = 0;
-				if (b + 4 <= nbytes) {
-					__builtin_memcpy(&v, h + b, 4);
-				} else {
-					for (uint32_t q = 0; q < 4; q++)
-						if (b + q < nbytes)
-							v |= (uint32_t) h[b + q] << (8 * q);
+			const uint8_t *src = a.in + d.src;
+			const int64_t nby = (int64_t) (d.nbits >> 3);
+#pragma unroll
+			for (int q = 0; q < 5; q++) {
+				const uint32_t j = tid + q * HT;
+				const int64_t rb = 4ll * j - (int64_t) (S >> 3);
+				if (j < ndw) {
+					if ((rb >= 0 || t) && rb < nby && rb + 4 > nby) { // the dword that straddles the end of the payload
+						for (int64_t i = 0; rb + i < nby; i++)
+							v[q] |= (uint32_t) src[rb + i] << (8 * i);
+					}
+					lbits[la(j)] = v[q];
+					if ((j & 63u) == 0 && j)
+						lbits[la(j) - 1] = v[q];
 				}
-				lbits[la(j)] = v;
-				if ((j & 63u) == 0 && j)
-					lbits[la(j) - 1] = v;
 			}
 		}
 		__syncthreads();
 		HSTAMP(1); // stage
 
-		// ---- pass 0: from the first bit of the own subsequence (thread 0 of the read's first tile: exact)
+		// ---- pass 0: image subsequence tid from its first bit
 		{
 			uint32_t c;
-			sE[tid] = huff_run<false>(lbits, lut, lut2, l2off, l2bits, a.huff, sub0, sub0 + S, nbits, c, nullptr);
-			sS[tid] = HNONE;
-			sC[tid] = 0;
+			uint32_t e = huff_run<false>(lbits, lut, lut2, l2off, l2bits, a.huff, tid * S, (tid + 1) * S, nbits, c, nullptr);
+			if (e == HEND && (tid + 1) * S < nbits)
+				e = (tid + 1) * S; // a guess that ran into a bit pattern that is no code: any guess will do
+			sE[tid] = (t == 0 && tid == 0) ? S : (e == HEND ? PE_END : e); // a read's first tile starts at its bit 0
+			sS[tid] = (uint8_t) ST_NONE; // the first round decodes everybody (with symbols)
 		}
 		HSTAMP(2); // pass 0
-		converge(0, nbits);
-		HSTAMP(3); // rounds A
+		converge(nbits);
+		HSTAMP(3); // rounds
 
-		// ---- hint for the successor; own start from the predecessor's hint
-		uint32_t pos0 = 0;
-		if (!last && tid == 0) {
-			const uint32_t el = sE[HT - 1];
-			__hip_atomic_store(a.hhint + k, HINT_READY | (el == HEND ? HINT_END : el - TB), __ATOMIC_RELAXED,
-					   __HIP_MEMORY_SCOPE_AGENT);
-		}
-		if (t) {
-			if (tid == 0)
-				s_hint = poll32(a.hhint + k - 1);
-			__syncthreads();
-			HSTAMP(4); // hint wait
-			const uint32_t hv = s_hint;
-			pos0 = (hv & HINT_END) ? HEND : (hv & 0xFFu);
-			if (pos0 == HEND) { // the stream ended before this tile
-				sS[tid] = HEND;
-				sE[tid] = HEND;
-				sC[tid] = 0;
-			} else {
-				converge(pos0, nbits);
-			}
-		}
-
-		HSTAMP(5); // rounds B
+		// ---- offsets, look-back, (rarely) another convergence
 		uint32_t cnt, excl, total;
 		uint64_t cum_prev = 0;
 		for (;;) {
-			// ---- offsets: exclusive prefix of the counts over the workgroup
-			__syncthreads();
-			cnt = sC[tid];
+			// exclusive prefix of the counts over the workgroup
+			cnt = sE[tid + 1] >> 24;
 			uint32_t inc = cnt;
 #pragma unroll
 			for (int dd = 1; dd < 64; dd <<= 1) {
@@ -344,85 +405,80 @@ __global__ __launch_bounds__(HUF_HT) void k_huff_decode_tiles(DecodeArgs a)
 				total += x;
 			}
 			excl = base + inc - cnt;
-
-			// ---- FINAL chain: wait for the predecessor, publish {end, count} for the successor
-			bool redo = false;
-			if (tid == 0) {
-				uint64_t fin = FIN_READY; // first tile: starts at bit 0, nothing before it
-				if (t)
-					fin = poll64(a.hfin + k - 1);
-				const uint32_t el = sE[HT - 1];
-				const uint32_t ptrue = (fin & FIN_END) ? HEND : (uint32_t) ((fin >> 32) & 0xFFu);
-				if (t && ptrue != pos0) {
-					fin |= 1ull << 61; // the hint was wrong: converge again from the true start
-				} else if (!last) {
-					const uint64_t cum = (fin & 0xFFFFFFFFull) + total;
-					__hip_atomic_store(a.hfin + k,
-							   FIN_READY | (el == HEND ? FIN_END : ((uint64_t) (el - TB) << 32)) |
-								   (cum > 0xFFFFFFFFull ? 0xFFFFFFFFull : cum),
-							   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (tid < 64) { // wave 0
+				const uint32_t pe = sE[HT], p0 = sE[0];
+				const uint64_t ge = (pe & PE_END) ? GP_END : ((pe & 0xFFFFFu) - (TB + S));
+				const uint32_t my_s = (p0 & PE_END) ? GP_END : ((p0 & 0xFFFFFu) - S);
+				uint64_t res;
+				if (t == 0) {
+					if (!last && lane == 0)
+						gran_st(a.hgran + k, GR_PFX | (ge << 48) | total);
+					res = LB_DONE;
+				} else {
+					if (!last && lane == 0)
+						gran_st(a.hgran + k, GR_AGG | ((uint64_t) my_s << 56) | (ge << 48) | total);
+					res = tile_lookback(a.hgran, k, t, my_s);
+					if ((res & LB_DONE) && !last && lane == 0) {
+						const uint64_t cum = (res & 0xFFFFFFFFull) + total;
+						gran_st(a.hgran + k, GR_PFX | (ge << 48) | (cum > 0xFFFFFFFFull ? 0xFFFFFFFFull : cum));
+					}
 				}
-				s_fin = fin;
+				if (lane == 0) {
+					s_res = res;
+					if (!(res & LB_DONE)) // the predecessor ends elsewhere: that is thread 0's start
+						sE[0] = (uint32_t) res == GP_END ? PE_END : S + (uint32_t) res;
+				}
 			}
 			__syncthreads();
-			HSTAMP(6); // prefix + final wait
-			const uint64_t fin = s_fin;
-			cum_prev = fin & 0xFFFFFFFFull;
-			redo = (fin >> 61) & 1ull;
-			if (!redo)
+			const uint64_t res = s_res;
+			HSTAMP(4); // prefix sum + look-back
+			if (res & LB_DONE) {
+				cum_prev = res & 0xFFFFFFFFull;
 				break;
-			HCOUNT(10, 1);
-			pos0 = (fin & FIN_END) ? HEND : (uint32_t) ((fin >> 32) & 0xFFu);
-			if (pos0 == HEND) {
-				sS[tid] = HEND;
-				sE[tid] = HEND;
-				sC[tid] = 0;
-			} else {
-				converge(pos0, nbits);
 			}
+			HCOUNT(10, 1);
+			if ((uint32_t) res == GP_END) { // the stream ended before this tile
+				sS[tid] = (uint8_t) ST_END;
+				sE[tid + 1] = PE_END;
+				__syncthreads();
+			} else {
+				converge(nbits);
+			}
+			HSTAMP(5); // rounds, corrected start
 		}
 
 		// ---- output: this tile delivers symbols [cum_prev, cum_prev + total) of the read, cut at `want`
 		const uint32_t o0 = cum_prev < want ? (uint32_t) cum_prev : want;
 		const uint32_t room = want - o0;
 		const uint32_t take = total < room ? total : room;
-		uint8_t *dst = low + o0;
-		const uint32_t skip = (uint32_t) ((uintptr_t) dst & 15);
-		uint8_t *g = dst - skip; // 16-byte aligned; obuf[b] <-> g[b]
 		{
 			const uint32_t nmine = excl < take ? (cnt < take - excl ? cnt : take - excl) : 0u;
-			const uint32_t *sl = reinterpret_cast<const uint32_t *>(myslot);
-			uint8_t *d = obuf + skip + excl;
-			for (uint32_t q = 0; q < nmine; q += 4) {
+			const uint32_t *sl = reinterpret_cast<const uint32_t *>(slots + tid * HSLOT);
+			uint8_t *dst = low + o0 + excl;
+			uint32_t q = 0;
+			for (; q + 4 <= nmine; q += 4) {
 				const uint32_t w = sl[q >> 2];
-				d[q] = (uint8_t) w;
-				if (q + 1 < nmine)
-					d[q + 1] = (uint8_t) (w >> 8);
-				if (q + 2 < nmine)
-					d[q + 2] = (uint8_t) (w >> 16);
-				if (q + 3 < nmine)
-					d[q + 3] = (uint8_t) (w >> 24);
+				__builtin_memcpy(dst + q, &w, 4);
 			}
-		}
-		__syncthreads();
-		{
-			const uint32_t tot = skip + take;
-			for (uint32_t c = tid; c * 16 < tot; c += HT) {
-				const uint32_t lo = c * 16;
-				if (lo >= skip && lo + 16 <= tot) {
-					reinterpret_cast<uint4 *>(g)[c] = reinterpret_cast<const uint4 *>(obuf)[c];
-				} else {
-					const uint32_t b0 = lo > skip ? lo : skip;
-					const uint32_t b1 = lo + 16 < tot ? lo + 16 : tot;
-					for (uint32_t b = b0; b < b1; b++)
-						g[b] = obuf[b];
-				}
+			if (q < nmine) {
+				const uint32_t w = sl[q >> 2];
+				dst[q] = (uint8_t) w;
+				if (q + 1 < nmine)
+					dst[q + 1] = (uint8_t) (w >> 8);
+				if (q + 2 < nmine)
+					dst[q + 2] = (uint8_t) (w >> 16);
 			}
 		}
 		if (last && tid == 0)
 			a.meta[r].nlow = o0 + take; // what huffman_decode_memory delivered
 		HSTAMP(7); // output
+		__syncthreads(); // this tile's LDS is no longer in use
 	}
+#ifdef HUF_DEBUG
+	if (threadIdx.x == 0)
+		for (int i = 0; i < 12; i++)
+			atomicAdd(&g_hufdbg[i], acc_[i]);
+#endif
 }
 
 // Tiles of every read (one thread per read; runs after k_ex_parse): ids of one read are
@@ -458,13 +514,25 @@ __global__ __launch_bounds__(256) void k_huff_tiles(DecodeArgs a)
 	if (lane == 0 && wsum)
 		base = atomicAdd(&a.ctl->nchunks, wsum);
 	base = (uint32_t) __shfl((int) base, 0, 64) + inc - nt;
-	for (uint32_t t = 0; t < nt; t++) {
-		const uint32_t k = base + t;
-		if (k >= a.max_htiles)
-			break; // cannot happen: max_htiles is the same bound summed over the slots
-		a.htiles[k] = make_uint2(r, t | (t + 1 == nt ? 0x80000000u : 0u));
-		a.hhint[k] = 0;
-		a.hfin[k] = 0;
+	if (nt) {
+		const ReadMeta *m = a.meta + r;
+		const uint32_t hdr = m->hdr + m->seclen + 4;
+		const uint64_t nbytes64 = a.in_len[r] - hdr;
+		const uint64_t nbits = 8ull * (nbytes64 > 0x1FFFFFFFull ? 0x1FFFFFFFull : nbytes64);
+		for (uint32_t t = 0; t < nt; t++) {
+			const uint32_t k = base + t;
+			if (k >= a.max_htiles)
+				break; // cannot happen: max_htiles is the same bound summed over the slots
+			HufTile d;
+			d.src = a.in_off[r] + hdr + t * (TB / 8);
+			d.low = a.off[r];
+			d.nbits = (uint32_t) (nbits - t * TB);
+			d.t_last = t | (t + 1 == nt ? 0x80000000u : 0u);
+			d.read = r;
+			d.want = m->nlow;
+			a.htiles[k] = d;
+			a.hgran[k] = 0;
+		}
 	}
 }
 

@@ -30,7 +30,8 @@ struct ReadMeta {
 
 // Static-Huffman tables on the device (built on the host from the 256 {len,bits} pairs).
 constexpr int HUF_LUT_BITS = 12;
-constexpr int HUF_L2_ENTRIES = 4096;
+constexpr int HUF_L2_ENTRIES = 3072; // the NA12878 table needs 2848
+constexpr int HUF_L2_IDS = 64;       // long-code prefixes with a second-level table (the rest walk the trie)
 struct HuffDev {
 	uint32_t enc[256];                 // code bits (bit k = k-th emitted bit) | len << 24
 	uint16_t lut[1 << HUF_LUT_BITS];   // sym | len << 8 for codes <= 12 bits, 0xFFFF: walk the trie
@@ -53,7 +54,7 @@ constexpr uint32_t HUF_LONG = 1u << 30;
 // parallel Huffman decode (press_huffman.hip): tiles of HUF_HT subsequences, one workgroup each
 constexpr int HUF_HT = 512;     // threads per workgroup = subsequences per tile
 constexpr int HUF_HSYM = 32;    // most codes that can start in one subsequence
-constexpr uint32_t HUF_GRID = 512; // persistent workgroups (2 per CU: 78 KB of LDS each)
+constexpr uint32_t HUF_GRID = 768; // persistent workgroups (3 per CU: 53 KB of LDS each)
 
 // ---- chunked (v2) svb kernels: a read is cut into chunks of CHUNK samples, one workgroup
 // per chunk; chunks of a read are chained by a decoupled look-back over 8-byte granules.
@@ -100,6 +101,15 @@ struct BatchArgs {
 	uint32_t max_chunks;      // >= sum over reads of ceil(n / CHUNK)
 };
 
+struct HufTile {             // one tile of a read's Huffman payload (press_huffman.hip), 32 bytes
+	uint64_t src;        // byte offset in the compressed arena of the tile's first payload byte
+	uint64_t low;        // offset in DecodeArgs::low of the read's one-byte stream
+	uint32_t nbits;      // payload bits from the tile's first bit to the end of the payload
+	uint32_t t_last;     // tile index in the read | (no tile follows) << 31
+	uint32_t read;
+	uint32_t want;       // codes the read's header announces
+};
+
 struct DecodeArgs {
 	const uint8_t *in;        // compressed arena
 	const uint64_t *in_off;   // [nreads]
@@ -121,9 +131,8 @@ struct DecodeArgs {
 	uint32_t *first_chunk;    // [nreads] id of the first chunk of read r
 	uint32_t max_chunks;
 	// Huffman tiles (press_huffman.hip)
-	uint2 *htiles;            // [max_htiles] {read, tile index in the read | last << 31}
-	uint32_t *hhint;          // [max_htiles] speculative end position of a tile
-	uint64_t *hfin;           // [max_htiles] final {end position, symbols so far}
+	HufTile *htiles;          // [max_htiles]
+	uint64_t *hgran;          // [max_htiles] look-back granules
 	uint32_t max_htiles;
 };
 
