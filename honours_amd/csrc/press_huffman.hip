@@ -44,7 +44,7 @@ constexpr int HSLOT = 36;              // bytes per private symbol slot: HSYM + 
 constexpr int HLB_DW = 2096;           // LDS dwords of the bit image (one subsequence before the tile + 2048 + reach of the last code, skewed)
 // packed per-thread result: position (20 bits) | END << 20 | codes << 24
 constexpr uint32_t PE_END = 1u << 20;
-constexpr uint32_t ST_NONE = 0xFFu, ST_END = 0xFEu; // sS: start relative to the subsequence, or these
+constexpr uint32_t ST_END = 0xFEu; // sS: start relative to the subsequence, or this
 // look-back granules: state << 62 | assumed start << 56 | end << 48 | codes; positions are
 // relative to the tile boundary (0..23), 63 = the stream has ended
 constexpr uint64_t GR_AGG = 1ull << 62, GR_PFX = 2ull << 62;
@@ -57,24 +57,30 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t) __bu
 // ds_read2_b32), and the 64 lanes of a wave - one subsequence apart - hit 64 different banks.
 __device__ __forceinline__ uint32_t la(uint32_t j) { return j + (j >> 6); }
 
-// Decode the codes that start in [start, sub_end) of the tile (bit positions relative to
-// the tile); returns where the next code starts, or HEND.  nbits = end of the payload.
+// Decode the codes that start in [start, sub_end) of the image (bit positions relative to
+// the image); returns where the next code starts, or HEND.  nbits = end of the payload.
 // WRITE: symbols go to `slot`, their number to `cnt`.
+// LEAD: the codes that start below `mid` are only a run-up from a guessed position - not
+// written, not counted; `first` returns where the first code at or after `mid` starts (HEND if
+// the payload ends before).  A run-up that hits a bit pattern that is no code restarts at mid.
 // The lane keeps a 64-bit window {hi, lo} of the stream in registers and fetches the dword
 // after it while the table lookup is in flight, so a step costs one LDS round trip.
-template <bool WRITE>
+template <bool WRITE, bool LEAD>
 __device__ __forceinline__ uint32_t huff_run(const uint32_t *lbits, const uint32_t *lut, const uint16_t *lut2,
 					     const uint16_t *l2off, const uint8_t *l2bits, const HuffDev *hd,
-					     uint32_t start, uint32_t sub_end, uint32_t nbits, uint32_t &cnt, uint8_t *slot)
+					     uint32_t start, uint32_t mid, uint32_t sub_end, uint32_t nbits, uint32_t &cnt,
+					     uint8_t *slot, uint32_t &first)
 {
 	bool bad = start == HEND;
 	uint32_t p = bad ? 0u : start;
 	uint32_t lim = sub_end < nbits ? sub_end : nbits; // codes must START below this
 	if (bad)
 		lim = 0;
+	const uint32_t lim1 = mid < nbits ? mid : nbits;  // ... run-up codes below this
 	uint32_t c = 0;
 	uint32_t j = p >> 5;
 	uint32_t lo = lbits[la(j)], hi = lbits[la(j) + 1];
+	uint32_t f = p;
 	// wave-uniform and predicated: lanes need different numbers of steps, and per-lane
 	// branches cost more than the few masked operations
 	for (;;) {
@@ -82,6 +88,7 @@ __device__ __forceinline__ uint32_t huff_run(const uint32_t *lbits, const uint32
 		if (!__any(act))
 			break;
 		if (act) {
+			const bool own = !LEAD || p >= mid;
 			const uint32_t nxt = lbits[la(j + 2)];
 			// 32 stream bits from position p (codes are at most 24 bits long)
 			const uint32_t wnd = __builtin_amdgcn_alignbit(hi, lo, p & 31);
@@ -104,24 +111,33 @@ __device__ __forceinline__ uint32_t huff_run(const uint32_t *lbits, const uint32
 					ok = node >= 0 && hd->leaf[node] >= 0;
 					sym = ok ? (uint32_t) hd->leaf[node] : 0u;
 				}
-				if (!ok) { // no such code: the reference stops here
-					bad = true;
-					lim = 0;
+				if (!ok) {
 					len = 0;
+					if (LEAD && !own) { // a guess went wrong: any guess will do
+						p = mid;
+						j = p >> 5;
+						lo = lbits[la(j)];
+						hi = lbits[la(j) + 1];
+					} else { // no such code: the reference stops here
+						bad = true;
+						lim = 0;
+					}
 				}
 				e = sym | (len << 16) | (len << 21) | (ok ? (1u << 26) : 0u);
 			}
 			// e = sym1 | sym2 << 8 | len1 << 16 | (len1 + len2) << 21 | (codes: 1 or 2) << 26; the second
-			// code counts only if it starts inside this subsequence
+			// code counts only if it starts inside this subsequence (run-up: below mid)
 			const uint32_t len1 = (e >> 16) & 0x1Fu;
-			const bool both = p + len1 < lim;
-			if (WRITE) {
+			const bool both = p + len1 < (own ? lim : lim1);
+			if (WRITE && own) {
 				slot[c] = (uint8_t) e;
 				slot[c + 1] = (uint8_t) (e >> 8);
 				const uint32_t n2 = e >> 26;
 				c += both ? n2 : (n2 ? 1u : 0u);
 			}
 			p += both ? ((e >> 21) & 0x1Fu) : len1;
+			if (LEAD && !own)
+				f = p;
 			const uint32_t jn = p >> 5; // a step crosses at most one dword
 			if (jn != j) {
 				lo = hi;
@@ -131,11 +147,25 @@ __device__ __forceinline__ uint32_t huff_run(const uint32_t *lbits, const uint32
 		}
 	}
 	if (!bad && p > nbits) { // the last code ran off the end of the input: not delivered
-		c -= 1;
+		if (c)
+			c -= 1;
 		bad = true;
 	}
 	cnt = c;
+	first = (LEAD && f < mid) ? HEND : f; // the payload ended inside the run-up
 	return bad ? HEND : (p >= nbits && p < sub_end ? HEND : p);
+}
+
+// inclusive scan over the 64 lanes of a wave (DPP row shifts + row broadcasts)
+__device__ __forceinline__ uint32_t wave_scan(uint32_t v)
+{
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, true); // row_shr:1
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, true); // row_shr:2
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, true); // row_shr:4
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, true); // row_shr:8
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
+	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
+	return v;
 }
 
 __device__ __forceinline__ uint64_t gran_ld(uint64_t *g)
@@ -238,7 +268,7 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 	__shared__ uint8_t sS[HT];      // the start (relative to its subsequence) thread i's result was decoded from
 	__shared__ uint16_t lst[HT];    // compacted list of threads whose start changed: id | start << 9 | END << 14
 	__shared__ uint32_t lst_n[2];
-	__shared__ uint32_t wtot[HT / 64];
+	__shared__ uint32_t wtot[2][HT / 64];
 	__shared__ uint32_t s_ticket;
 	__shared__ uint64_t s_res;
 	__shared__ __attribute__((aligned(16))) uint8_t slots[HT * HSLOT];
@@ -264,16 +294,22 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 	const uint32_t nalloc = uniform(a.ctl->nchunks);
 	const uint32_t ntiles = nalloc < a.max_htiles ? nalloc : a.max_htiles;
 	const uint32_t ndw = (TB + S) / 32 + 4; // dwords of the image
-	uint32_t round = 0;                     // parity selects lst_n
+	uint32_t round = 0;                     // parity selects lst_n / wtot
+	uint32_t cnt = 0, excl = 0, total = 0;  // own codes, codes of the threads before, codes of the tile
 
 	// converge: repeat "take the left neighbour's end as start, decode again if it changed"
-	// until nothing changes.  Barriers inside; all threads call it.
+	// until nothing changes; leaves the prefix sums of the counts in cnt / excl / total.
+	// Barriers inside; all threads call it.
 	auto converge = [&](uint32_t nbits) {
 		for (;;) {
 			const uint32_t par = round & 1u;
 			round++;
 			if (tid == 0)
 				lst_n[par] = 0;
+			cnt = sE[tid + 1] >> 24; // own write, or settled by the barrier that ended the last round
+			const uint32_t inc = wave_scan(cnt);
+			if (lane == 63)
+				wtot[par][tid >> 6] = inc;
 			__syncthreads();
 			const uint32_t pe = sE[tid];
 			const uint32_t code = (pe & PE_END) ? ST_END : ((pe & 0xFFFFFu) - (tid + 1) * S);
@@ -289,8 +325,19 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 			}
 			__syncthreads();
 			const uint32_t nch = lst_n[par];
-			if (nch == 0)
+			if (nch == 0) {
+				uint32_t before = 0;
+				total = 0;
+#pragma unroll
+				for (int w2 = 0; w2 < HT / 64; w2++) {
+					const uint32_t x = wtot[par][w2];
+					if (w2 < (int) (tid >> 6))
+						before += x;
+					total += x;
+				}
+				excl = before + inc - cnt;
 				break;
+			}
 			HCOUNT(9, 1);
 			HCOUNT(11, nch);
 			if ((tid & ~63u) < nch) { // whole waves beyond the list skip
@@ -299,14 +346,16 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 				const uint32_t u = ent & 511u;
 				const bool end = (ent >> 14) & 1u;
 				const uint32_t rel = (ent >> 9) & 31u;
-				uint32_t c;
-				const uint32_t e = huff_run<true>(lbits, lut, lut2, l2off, l2bits, a.huff,
-								  end ? HEND : (u + 1) * S + rel, (u + 2) * S, nbits, c, slots + u * HSLOT);
+				uint32_t c, f;
+				const uint32_t st = end ? HEND : (u + 1) * S + rel;
+				const uint32_t e = huff_run<true, false>(lbits, lut, lut2, l2off, l2bits, a.huff, st, st, (u + 2) * S, nbits,
+									 c, slots + u * HSLOT, f);
 				if (mine) {
 					sS[u] = (uint8_t) (end ? ST_END : rel);
 					sE[u + 1] = (e == HEND ? PE_END : e) | (c << 24);
 				}
 			}
+			__syncthreads(); // counts settled before the next round's scan
 		}
 	};
 
@@ -325,14 +374,14 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 		}
 	};
 
-	for (;;) {
-		if (tid == 0)
-			s_ticket = atomicAdd(&a.ctl->ticket, 1u);
-		__syncthreads();
-		const uint32_t k = s_ticket;
-		if (k >= ntiles)
-			break;
-		const HufTile d = a.htiles[k];
+	if (tid == 0)
+		s_ticket = atomicAdd(&a.ctl->ticket, 1u);
+	__syncthreads();
+	uint32_t k = s_ticket;
+	HufTile d;
+	if (k < ntiles)
+		d = a.htiles[k];
+	while (k < ntiles) {
 		uint32_t v[5];
 		load_bits(d, v);
 		HSTAMP(0); // ticket
@@ -366,45 +415,26 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 		__syncthreads();
 		HSTAMP(1); // stage
 
-		// ---- pass 0: image subsequence tid from its first bit
+		// ---- first pass: run up through image subsequence tid from its first bit, then the own
+		// subsequence tid + 1 with symbols (a read's first tile starts exactly at its bit 0)
 		{
-			uint32_t c;
-			uint32_t e = huff_run<false>(lbits, lut, lut2, l2off, l2bits, a.huff, tid * S, (tid + 1) * S, nbits, c, nullptr);
-			if (e == HEND && (tid + 1) * S < nbits)
-				e = (tid + 1) * S; // a guess that ran into a bit pattern that is no code: any guess will do
-			sE[tid] = (t == 0 && tid == 0) ? S : (e == HEND ? PE_END : e); // a read's first tile starts at its bit 0
-			sS[tid] = (uint8_t) ST_NONE; // the first round decodes everybody (with symbols)
+			uint32_t c, f;
+			const bool exact = t == 0 && tid == 0;
+			const uint32_t e = huff_run<true, true>(lbits, lut, lut2, l2off, l2bits, a.huff, exact ? S : tid * S, (tid + 1) * S,
+								(tid + 2) * S, nbits, c, slots + tid * HSLOT, f);
+			sS[tid] = (uint8_t) (f == HEND ? ST_END : f - (tid + 1) * S);
+			sE[tid + 1] = (e == HEND ? PE_END : e) | (c << 24);
+			if (tid == 0)
+				sE[0] = f == HEND ? PE_END : f; // the tile's guess of its own start
 		}
-		HSTAMP(2); // pass 0
+		HSTAMP(2); // first pass
 		converge(nbits);
 		HSTAMP(3); // rounds
 
-		// ---- offsets, look-back, (rarely) another convergence
-		uint32_t cnt, excl, total;
+		// ---- look-back, (rarely) another convergence
 		uint64_t cum_prev = 0;
+		uint32_t kn = 0xFFFFFFFFu;
 		for (;;) {
-			// exclusive prefix of the counts over the workgroup
-			cnt = sE[tid + 1] >> 24;
-			uint32_t inc = cnt;
-#pragma unroll
-			for (int dd = 1; dd < 64; dd <<= 1) {
-				const uint32_t t2 = (uint32_t) __shfl_up((int) inc, dd, 64);
-				if ((int) lane >= dd)
-					inc += t2;
-			}
-			if (lane == 63)
-				wtot[tid >> 6] = inc;
-			__syncthreads();
-			uint32_t base = 0;
-			total = 0;
-#pragma unroll
-			for (int w2 = 0; w2 < HT / 64; w2++) {
-				const uint32_t x = wtot[w2];
-				if (w2 < (int) (tid >> 6))
-					base += x;
-				total += x;
-			}
-			excl = base + inc - cnt;
 			if (tid < 64) { // wave 0
 				const uint32_t pe = sE[HT], p0 = sE[0];
 				const uint64_t ge = (pe & PE_END) ? GP_END : ((pe & 0xFFFFFu) - (TB + S));
@@ -425,15 +455,18 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 				}
 				if (lane == 0) {
 					s_res = res;
-					if (!(res & LB_DONE)) // the predecessor ends elsewhere: that is thread 0's start
+					if (res & LB_DONE) // nothing left to wait for: the next tile (its descriptor arrives during the output)
+						s_ticket = atomicAdd(&a.ctl->ticket, 1u);
+					else // the predecessor ends elsewhere: that is thread 0's start
 						sE[0] = (uint32_t) res == GP_END ? PE_END : S + (uint32_t) res;
 				}
 			}
 			__syncthreads();
 			const uint64_t res = s_res;
-			HSTAMP(4); // prefix sum + look-back
+			HSTAMP(4); // look-back
 			if (res & LB_DONE) {
 				cum_prev = res & 0xFFFFFFFFull;
+				kn = s_ticket;
 				break;
 			}
 			HCOUNT(10, 1);
@@ -441,11 +474,13 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 				sS[tid] = (uint8_t) ST_END;
 				sE[tid + 1] = PE_END;
 				__syncthreads();
-			} else {
-				converge(nbits);
 			}
+			converge(nbits);
 			HSTAMP(5); // rounds, corrected start
 		}
+		HufTile dn;
+		if (kn < ntiles)
+			dn = a.htiles[kn];
 
 		// ---- output: this tile delivers symbols [cum_prev, cum_prev + total) of the read, cut at `want`
 		const uint32_t o0 = cum_prev < want ? (uint32_t) cum_prev : want;
@@ -472,6 +507,8 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 		if (last && tid == 0)
 			a.meta[r].nlow = o0 + take; // what huffman_decode_memory delivered
 		HSTAMP(7); // output
+		k = kn;
+		d = dn;
 		__syncthreads(); // this tile's LDS is no longer in use
 	}
 #ifdef HUF_DEBUG
