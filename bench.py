@@ -150,7 +150,7 @@ def main():
         alg = raw_bytes + comp_bytes
         kern = {"svb12_zd": ("k_svb_encode_chunked<false,true>", "k_svb_decode_chunked<false,true>"),
                 "svb_zd": ("k_svb_encode_chunked<true,true>", "k_svb_decode_chunked<true,true>"),
-                "shuffman_vbe21_zd": ("k_low_encode<true>", "k_huff_decode_par")}.get(
+                "shuffman_vbe21_zd": ("k_huff_encode_chunked", "k_huff_decode_tiles")}.get(
                     m, ("k_low_encode_chunked", "k_low_decode_chunked<false>"))
         traffic = measured_traffic(m, R, args.seed, args.fixed_len)
 

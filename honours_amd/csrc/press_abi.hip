@@ -80,7 +80,7 @@ struct Ctx {
 	hipStream_t user = nullptr;
 	bool use_user = false;
 	// scratch shared by both modes
-	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, hgran;
+	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, hgran, gran2;
 	int use_v1 = -1; // PRESS_HIP_V1=1 selects the one-workgroup-per-read svb kernels (A/B)
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn;
@@ -324,6 +324,11 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 	if (is_ex(method)) {
 		if (g.ex_pos.reserve((total_samples + 64) * 4) || g.ex_val.reserve((total_samples + 64) * 4))
 			return PRESS_HIP_EHIP;
+		if (!decode && is_shuff(method)) {
+			const size_t mc = max_chunks_of(total_samples, nreads);
+			if (g.gran2.reserve(mc * sizeof(uint64_t)))
+				return PRESS_HIP_EHIP;
+		}
 		if (decode && is_shuff(method)) {
 			const size_t mt = max_htiles_of(total_samples, nreads);
 			if (g.low.reserve(total_samples + 64) || g.htiles.reserve(mt * sizeof(HufTile)) ||
@@ -445,7 +450,7 @@ extern "C" void press_hip_shutdown(void)
 		return;
 	(void) hipSetDevice(g.device);
 	(void) hipStreamSynchronize(g.own);
-	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.chunks, &g.gran, &g.ctl, &g.first_chunk, &g.htiles, &g.hgran, &g.sig, &g.off, &g.nsamp,
+	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.chunks, &g.gran, &g.ctl, &g.first_chunk, &g.htiles, &g.hgran, &g.gran2, &g.sig, &g.off, &g.nsamp,
 			  &g.arena, &g.arena_off, &g.lens, &g.lens2, &g.outn };
 	for (DevBuf *b : all)
 		b->release();
@@ -579,6 +584,8 @@ extern "C" int press_hip_press_batch(int method, const int16_t *sig, const uint6
 	a.gran = (uint64_t *) g.gran.p;
 	a.ctl = (ChunkCtl *) g.ctl.p;
 	a.max_chunks = max_chunks_of(total_samples, nreads);
+	if (is_shuff(method))
+		a.gran2 = (uint64_t *) g.gran2.p;
 
 	if (device_resident) {
 		if ((uintptr_t) sig & 15)

@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 						    const uint64_t *slot_off, const uint64_t *in_len,
 						    uint32_t nreads, ChunkDesc *chunks, uint64_t *gran,
 						    ChunkCtl *ctl, uint32_t max_chunks, uint64_t *out_len,
-						    uint32_t *out_n, uint32_t *first_chunk, ReadMeta *meta = nullptr)
+						    uint32_t *out_n, uint32_t *first_chunk, ReadMeta *meta = nullptr,
+						    uint64_t *gran2 = nullptr)
 {
 	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
 	uint32_t n = 0, nch = 0;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 			out_n[r] = 0;
 	}
 	const uint64_t o = off[r];
-	if (DEC)
+	if (first_chunk)
 		first_chunk[r] = first;
 	for (uint32_t j = 0; j < nch; j++) {
 		if (first + j >= max_chunks)
@@ -226,6 +227,8 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 		d.kmask[0] = d.kmask[1] = d.kmask[2] = d.kmask[3] = 0;
 		chunks[first + j] = d;
 		gran[first + j] = 0;
+		if (gran2)
+			gran2[first + j] = 0;
 	}
 }
 
@@ -1184,6 +1187,283 @@ __global__ __launch_bounds__(CWG) void k_low_encode_chunked(BatchArgs a)
 	}
 }
 
+// Pass B, static-Huffman stream (huffman.c:1184 + do_memory_encode :848: the codes packed
+// from bit 0 of each byte upwards - a little-endian bit stream).  Chunks in ticket order by a
+// persistent grid; what chains the chunks of a read is the number of code BITS in front of a
+// chunk (decoupled look-back over a.gran2, as for the exception counts):
+//   phase 1  every lane adds up the code lengths of its 128 samples, the workgroup publishes
+//            the chunk's total and wave 0 looks back for the bits in front of the chunk;
+//   phase 2  the four waves are independent: a wave knows the bit position Bq of its quarter,
+//            stages the codes of one 512-sample sub-tile at a time in a private LDS buffer
+//            (LDS atomic OR of code << bitpos) and copies the completed dwords out.
+// Who writes a byte shared by two quarters: the quarter that holds the byte's LAST bit; it
+// recomputes the few bits its predecessors put into that byte from the samples in front of
+// it.  The last, partial byte of a read and out_len are written by wave 0 of its last chunk.
+constexpr int HSTG = 400; // dwords per wave: carried bits (< 32) + 512 codes of at most 24 bits + spill
+
+__device__ __forceinline__ uint32_t zz16_dev(int32_t d)
+{
+	const int32_t s = (int32_t) (int16_t) d;
+	return (uint32_t) ((s << 1) ^ (s >> 15)) & 0xFFFFu;
+}
+
+// the last nb (1..7) bits of the code stream of samples [1, end) of a read: all 64 lanes call
+// it, every lane gets the value.  enc: the code table in LDS.
+__device__ __forceinline__ uint32_t huff_tail_bits(const int16_t *in, uint32_t end, uint32_t nb, const uint32_t *enc,
+						   int lane)
+{
+	uint32_t acc = 0, got = 0;
+	uint32_t pos = end; // samples [1, pos) are still to be looked at
+	while (got < nb && pos > 1) {
+		const int64_t i = (int64_t) pos - 64 + lane;
+		const bool valid = i >= 1;
+		uint32_t zv = 0xFFFFu;
+		if (valid)
+			zv = zz16_dev((int32_t) in[i] - (int32_t) in[i - 1]);
+		unsigned long long mask = __ballot(valid && zv <= 255u);
+		while (mask && got < nb) {
+			const int l = 63 - __builtin_clzll(mask);
+			const uint32_t e = enc[(uint32_t) __builtin_amdgcn_readlane((int) zv, l)];
+			const uint32_t len = e >> 24;
+			acc = (acc << len) | (e & 0xFFFFFFu); // an earlier value's code sits below the later ones
+			got += len;
+			mask &= ~(1ull << l);
+		}
+		pos = pos > 64 ? pos - 64 : 0;
+	}
+	return got >= nb ? (acc >> (got - nb)) & ((1u << nb) - 1u) : acc;
+}
+
+// which of a lane's 8 samples starting at i0 are one-byte values: inside [1, n), no exception
+__device__ __forceinline__ uint32_t low_mask(const uint4 &z, uint32_t i0, uint32_t n)
+{
+	uint32_t lowm = i0 + 8 <= n ? 0xFFu : (i0 < n ? (1u << (n - i0)) - 1u : 0u);
+	if (i0 == 0)
+		lowm &= ~1u;
+	if ((z.x | z.y | z.z | z.w) & 0xFF00FF00u)
+		lowm &= ~exc_mask(z, i0);
+	return lowm;
+}
+
+// raw samples of a lane's 8 samples of a sub-tile (zeros at or beyond n)
+__device__ __forceinline__ uint4 sub_load(const int16_t *in, uint32_t n, uint32_t i0)
+{
+	uint4 r = make_uint4(0, 0, 0, 0);
+	if (i0 < n)
+		r = *reinterpret_cast<const uint4 *>(in + i0);
+	return r;
+}
+
+// their zig-zag deltas (trans.c:75,215; q = 0).  carry = the sample in front of the sub-tile
+// in bits 16..31; returns the sub-tile's last sample the same way for the next one.
+__device__ __forceinline__ uint4 sub_zd(uint4 raw, uint32_t n, uint32_t i0, uint32_t &carry)
+{
+	uint32_t r[4] = { raw.x, raw.y, raw.z, raw.w };
+	const uint32_t nv = i0 + 8 <= n ? 8u : (i0 < n ? n - i0 : 0u);
+	if (nv < 8) {
+#pragma unroll
+		for (int h = 0; h < 4; h++) {
+			if (nv <= (uint32_t) (2 * h))
+				r[h] = 0;
+			else if (nv == (uint32_t) (2 * h + 1))
+				r[h] &= 0xFFFFu;
+		}
+	}
+	const uint32_t pw = prev_lane(r[3], carry);
+	uint32_t zz[4];
+	zz[0] = zd_pair(r[0], pw);
+	zz[1] = zd_pair(r[1], r[0]);
+	zz[2] = zd_pair(r[2], r[1]);
+	zz[3] = zd_pair(r[3], r[2]);
+	carry = (uint32_t) __builtin_amdgcn_readlane((int) r[3], 63);
+	if (nv < 8) { // deltas of samples beyond n are garbage
+#pragma unroll
+		for (int h = 0; h < 4; h++) {
+			if (nv <= (uint32_t) (2 * h))
+				zz[h] = 0;
+			else if (nv == (uint32_t) (2 * h + 1))
+				zz[h] &= 0xFFFFu;
+		}
+	}
+	return make_uint4(zz[0], zz[1], zz[2], zz[3]);
+}
+
+__global__ __launch_bounds__(CWG) void k_huff_encode_chunked(BatchArgs a)
+{
+	__shared__ uint32_t enc[256];
+	__shared__ uint32_t stg_all[4][HSTG];
+	__shared__ uint32_t s_ticket;
+	__shared__ uint32_t s_wbits[4];
+	__shared__ uint64_t s_before;
+
+	enc[threadIdx.x] = a.huff->enc[threadIdx.x];
+	for (uint32_t i = threadIdx.x; i < 4u * HSTG; i += CWG)
+		(&stg_all[0][0])[i] = 0;
+	const uint32_t nchunks = uni(a.ctl->nchunks);
+	const int lane = threadIdx.x & 63;
+	const int w = (int) uni(threadIdx.x >> 6);
+	uint32_t *stg = stg_all[w];
+	for (;;) {
+		if (threadIdx.x == 0)
+			s_ticket = atomicAdd(&a.ctl->ticket2, 1u);
+		__syncthreads();
+		const uint32_t t = uni(s_ticket);
+		if (t >= nchunks)
+			break;
+		const ChunkDesc *dp = a.chunks + t;
+		const ChunkU d = load_chunk(dp);
+		const ReadMeta *m = a.meta + d.read;
+		if (uni(m->status)) { // out_len = FAILED was written by k_ex_section; none of the read's chunks looks back
+			__syncthreads();
+			continue;
+		}
+		const uint32_t n = d.n;
+		const uint32_t first = d.j * CHUNK;
+		const bool last = first + CHUNK >= n;
+		const uint32_t ws = first + w * WAVE_SAMPLES;
+		const int16_t *in = a.sig + d.sig_off;
+		const uint32_t head = uni(m->hdr) + uni(m->seclen) + 4; // bytes in front of the payload
+		uint8_t *payload = a.out + d.out_base + head;
+		const uint64_t cap = uni64(a.out_off[d.read + 1]) - d.out_base;
+		uint32_t carry0 = 0; // the sample in front of the quarter
+		if (ws > 0 && ws < n)
+			carry0 = (uint32_t) (uint16_t) in[ws - 1] << 16;
+
+		// ---- phase 1: code bits of the quarter; the samples stream through, four sub-tiles in flight
+		uint32_t lbits = 0;
+		{
+			uint32_t carry = carry0;
+			uint4 raw[4];
+#pragma unroll
+			for (int k = 0; k < 4; k++)
+				raw[k] = sub_load(in, n, ws + k * SUB + lane * 8);
+#pragma unroll 1
+			for (int kk = 0; kk < CK; kk += 4) {
+				uint4 nxt[4];
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					nxt[k] = kk + 4 + k < CK ? sub_load(in, n, ws + (kk + 4 + k) * SUB + lane * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const uint32_t i0 = ws + (kk + k) * SUB + lane * 8;
+					const uint4 z = sub_zd(raw[k], n, i0, carry);
+					const uint32_t lowm = low_mask(z, i0, n);
+					const uint32_t zz[4] = { z.x, z.y, z.z, z.w };
+#pragma unroll
+					for (int h = 0; h < 8; h++) {
+						const uint32_t l = enc[(zz[h >> 1] >> (16 * (h & 1))) & 0xFFu] >> 24;
+						lbits += ((lowm >> h) & 1u) ? l : 0u;
+					}
+				}
+#pragma unroll
+				for (int k = 0; k < 4; k++)
+					raw[k] = nxt[k];
+			}
+		}
+		{
+			const uint32_t inc = wave_incl_scan_dpp(lbits);
+			if (lane == 63)
+				s_wbits[w] = inc;
+		}
+		__syncthreads();
+		const uint32_t q0 = uni(s_wbits[0]), q1 = uni(s_wbits[1]), q2 = uni(s_wbits[2]), q3 = uni(s_wbits[3]);
+		if (w == 0) {
+			const uint64_t before = lookback(a.gran2, t, d.j, (uint64_t) q0 + q1 + q2 + q3, last);
+			if (lane == 0)
+				s_before = before;
+			if (last) { // the read ends here: its length and its last, partial byte (zero padded, huffman.c:878)
+				const uint64_t bits = before + q0 + q1 + q2 + q3;
+				const uint64_t total = (uint64_t) head + (bits + 7) / 8;
+				const uint32_t nbt = (uint32_t) bits & 7u;
+				if (total <= cap && nbt) {
+					const uint32_t tb = huff_tail_bits(in, n, nbt, enc, lane);
+					if (lane == 0)
+						payload[bits >> 3] = (uint8_t) tb;
+				}
+				if (lane == 0)
+					a.out_len[d.read] = total <= cap ? total : CFAIL64;
+			}
+		}
+		__syncthreads();
+		const uint32_t mybits = w == 0 ? q0 : w == 1 ? q1 : w == 2 ? q2 : q3;
+		const uint64_t Bq = uni64(s_before) + (w > 0 ? q0 : 0u) + (w > 1 ? q1 : 0u) + (w > 2 ? q2 : 0u);
+		// ---- phase 2: the samples again (from L2); a quarter that would run past the slot writes
+		// nothing - the read fails
+		if (mybits && (uint64_t) head + (Bq + mybits + 7) / 8 <= cap) {
+			// the nb bits in front of Bq that share its byte
+			const uint32_t nb = (uint32_t) Bq & 7u;
+			if (nb) {
+				const uint32_t tb = huff_tail_bits(in, ws, nb, enc, lane);
+				if (lane == 0)
+					stg[0] = tb;
+			}
+			uint8_t *g = payload + (Bq >> 3); // byte of staging bit 0
+			uint32_t fill = nb;               // bits waiting at the front of the staging buffer
+			wave_lds_sync();
+			uint32_t carry = carry0;
+			uint4 raw = sub_load(in, n, ws + lane * 8);
+#pragma unroll 1
+			for (int k = 0; k < CK; k++) {
+				const uint32_t sub0 = ws + k * SUB;
+				if (sub0 >= n)
+					break;
+				const uint32_t i0 = sub0 + lane * 8;
+				const uint4 nxt = k + 1 < CK ? sub_load(in, n, i0 + SUB) : make_uint4(0, 0, 0, 0);
+				const uint4 z = sub_zd(raw, n, i0, carry);
+				raw = nxt;
+				const uint32_t lowm = low_mask(z, i0, n);
+				const uint32_t zz[4] = { z.x, z.y, z.z, z.w };
+				uint32_t e[8];
+				uint32_t lb = 0;
+#pragma unroll
+				for (int h = 0; h < 8; h++) {
+					e[h] = enc[(zz[h >> 1] >> (16 * (h & 1))) & 0xFFu];
+					lb += ((lowm >> h) & 1u) ? (e[h] >> 24) : 0u;
+				}
+				const uint32_t inc = wave_incl_scan_dpp(lb);
+				const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+				uint32_t pos = fill + inc - lb;
+#pragma unroll
+				for (int h = 0; h < 8; h++) {
+					if ((lowm >> h) & 1u) {
+						const uint64_t wv = (uint64_t) (e[h] & 0xFFFFFFu) << (pos & 31u);
+						if ((uint32_t) wv)
+							atomicOr(&stg[pos >> 5], (uint32_t) wv);
+						if ((uint32_t) (wv >> 32))
+							atomicOr(&stg[(pos >> 5) + 1], (uint32_t) (wv >> 32));
+						pos += e[h] >> 24;
+					}
+				}
+				wave_lds_sync();
+				// completed dwords out (unaligned 4-byte stores), the partial one to the front
+				const uint32_t total = fill + tot;
+				const uint32_t nfull = total >> 5;
+				for (uint32_t c = (uint32_t) lane; c < nfull; c += 64) {
+					const uint32_t v = stg[c];
+					stg[c] = 0;
+					__builtin_memcpy(g + 4ull * c, &v, 4);
+				}
+				if (nfull && lane == 0) {
+					const uint32_t tl = stg[nfull];
+					stg[nfull] = 0;
+					stg[0] = tl;
+				}
+				g += 4ull * nfull;
+				fill = total & 31u;
+				wave_lds_sync();
+			}
+			// whole bytes that are left; a partial last byte belongs to whoever holds its last bit
+			if (lane == 0) {
+				const uint32_t v = stg[0];
+				for (uint32_t b = 0; b < (fill >> 3); b++)
+					g[b] = (uint8_t) (v >> (8 * b));
+				stg[0] = 0;
+			}
+		}
+		__syncthreads(); // every wave has read s_ticket / s_before / s_wbits before they are overwritten
+	}
+}
+
 // ------------------------------------------------------------------ exception split decode, chunked
 //
 // Second half of vbe21_depress and siblings (press.c:2757-2771) fused with unzigdelta_u16_16
@@ -1514,8 +1794,7 @@ static void run_decode(const DecodeArgs &a, hipStream_t s)
 	ktime_end(1, s);
 }
 
-// exception-split encode with the chunked scan; pass B chunked for the plain stream, the v1
-// per-read kernel for the Huffman stream
+// exception-split encode: chunked scan, section per read, chunked pass B
 void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
 {
 	if (!a.nreads || !a.max_chunks)
@@ -1524,7 +1803,7 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL((k_chunk_prep<false, false>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
 			   a.nsamp, a.out_off, (const uint64_t *) nullptr, a.nreads, a.chunks, a.gran, a.ctl,
-			   a.max_chunks, a.out_len, (uint32_t *) nullptr, (uint32_t *) nullptr, a.meta);
+			   a.max_chunks, a.out_len, (uint32_t *) nullptr, (uint32_t *) nullptr, a.meta, huff ? a.gran2 : nullptr);
 	hipLaunchKernelGGL((k_ex_scan_chunked<false>), dim3(grid), dim3(CWG), 0, s, a);
 	if (fmt == EXF_EXZD) {
 		// second scan on the shifted samples for reads with q > 0 (fresh tickets and granules)
@@ -1536,7 +1815,7 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_
 	launch_ex_section(a, fmt, huff, s);
 	ktime_begin(0, s);
 	if (huff)
-		launch_low_encode_huff_v1(a, s);
+		hipLaunchKernelGGL(k_huff_encode_chunked, dim3(grid), dim3(CWG), 0, s, a);
 	else
 		hipLaunchKernelGGL(k_low_encode_chunked, dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	ktime_end(0, s);

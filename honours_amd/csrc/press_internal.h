@@ -99,6 +99,7 @@ struct BatchArgs {
 	uint64_t *gran;           // [max_chunks] look-back granules (zeroed per launch)
 	ChunkCtl *ctl;            // zeroed per launch
 	uint32_t max_chunks;      // >= sum over reads of ceil(n / CHUNK)
+	uint64_t *gran2;          // [max_chunks] look-back granules of the Huffman bit-count chain
 };
 
 struct HufTile {             // one tile of a read's Huffman payload (press_huffman.hip), 32 bytes
@@ -151,7 +152,6 @@ void launch_ex_parse_huff(const DecodeArgs &a, int fmt, bool huff, hipStream_t s
 void launch_huff_decode(const DecodeArgs &a, hipStream_t s);                       // press_huffman.hip
 // pieces of the v1 pipeline reused by the chunked one (press_kernels.hip)
 void launch_ex_section(const BatchArgs &a, int fmt, bool huff, hipStream_t s);
-void launch_low_encode_huff_v1(const BatchArgs &a, hipStream_t s);
 void launch_svb_decode(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s);
 // exception-split encode: scan (+ qts redo for ex-zd) -> section -> one-byte / Huffman stream
 void launch_ex_encode(const BatchArgs &a, int fmt, bool huff, hipStream_t s);

@@ -663,6 +663,13 @@ __global__ __launch_bounds__(64) void k_ex_section(BatchArgs a, int fmt, int huf
 	}
 	m->seclen = (uint32_t) seclen;
 	m->nlow = (uint32_t) nlow;
+	if (huff == 2) { // chunked Huffman pass B: the payload follows the symbol count (huffman.c:1203: htonl)
+		uint8_t *h = out + hdr + seclen;
+		h[0] = (uint8_t) (nlow >> 24);
+		h[1] = (uint8_t) (nlow >> 16);
+		h[2] = (uint8_t) (nlow >> 8);
+		h[3] = (uint8_t) nlow;
+	}
 	m->status = 0;
 	if (!huff)
 		a.out_len[r] = (uint64_t) hdr + seclen + nlow; // the Huffman pass B knows its own length
@@ -1118,18 +1125,14 @@ void launch_svb_decode(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s
 
 void launch_ex_section(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_ex_section, dim3(a.nreads), dim3(64), 0, s, a, fmt, huff ? 1 : 0);
+	hipLaunchKernelGGL(k_ex_section, dim3(a.nreads), dim3(64), 0, s, a, fmt, huff ? 2 : 0);
 }
 
-void launch_low_encode_huff_v1(const BatchArgs &a, hipStream_t s)
+void launch_ex_encode(const BatchArgs &a0, int fmt, bool huff, hipStream_t s)
 {
-	hipLaunchKernelGGL((k_low_encode<true>), dim3(a.nreads), dim3(WG), 0, s, a);
-}
-
-void launch_ex_encode(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
-{
-	if (!a.nreads)
+	if (!a0.nreads)
 		return;
+	const BatchArgs &a = a0;
 	const dim3 grid(a.nreads);
 	hipLaunchKernelGGL((k_ex_scan<false>), grid, dim3(WG), 0, s, a);
 	if (fmt == EXF_EXZD)
