@@ -164,6 +164,17 @@ def default_table():
     return _table
 
 
+def use_table(path=TABLE_PATH):
+    """Make `path` the table of the shuffman_* calls: the caller-owned objects the per-read
+    functions receive, and the batch API's table (press_hip_load_table_file)."""
+    global _table
+    new = HuffmanTable(path)
+    if _table is not None:
+        _table.close()
+    _table = new
+    load_table(path)
+
+
 def bound(method, n):
     """X_bound(n): what press/test.c mallocs for the compressed read."""
     lib = load_library()

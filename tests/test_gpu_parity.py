@@ -251,3 +251,86 @@ def test_batch_device_resident_roundtrip(oracle):
         torch.cuda.synchronize()
         assert np.array_equal(d_outn.cpu().numpy(), n_np.astype(np.int32)), m
         assert torch.equal(d_back[:total], sig_al[:total]), m
+
+
+# ---------------------------------------------------------------- static Huffman: tables other than NA12878
+
+def _canonical_table(lens):
+    """prefix code with the given lengths (Kraft sum <= 1): canonical codes, emitted MSB first
+    -> bit k of `bits` = k-th emitted bit (the table file's order, huffman.c:427-439)"""
+    order = sorted(range(256), key=lambda s: (lens[s], s))
+    code, prev = 0, lens[order[0]]
+    bits = [0] * 256
+    for s in order:
+        code <<= lens[s] - prev
+        prev = lens[s]
+        bits[s] = int(format(code, "0%db" % lens[s])[::-1], 2)  # MSB-first emission -> LSB-first integer
+        code += 1
+    assert code <= 1 << prev
+    return bits
+
+
+def _write_table(path, lens, bits):
+    """the reference's table file (huffman.c:549 read_code_table): u32 BE count, u32 (unused here),
+    then per symbol: symbol, number of bits, the bits packed from bit 0 of each byte upwards"""
+    b = bytearray((256).to_bytes(4, "big") + bytes(4))
+    for s in range(256):
+        b += bytes([s, lens[s]]) + bits[s].to_bytes((lens[s] + 7) // 8, "little")
+    with open(path, "wb") as f:
+        f.write(bytes(b))
+
+
+TABLES = {
+    # shortest code 1 bit -> 32-bit subsequences; one 9-bit pattern is no code at all
+    "min1_incomplete": [1] + [9] * 255,
+    # shortest code 2 bits -> 64-bit subsequences; incomplete as well
+    "min2_incomplete": [2, 2, 2] + [10] * 253,
+    # long codes: second-level tables and, beyond 64 long prefixes, the trie walk
+    "long_codes": [6] * 16 + [7] * 32 + [8] * 64 + [9] * 32 + [10] * 32 + [13] * 16 + [16] * 16 + [20] * 16
+                  + [22] * 16 + [24] * 16,
+}
+
+
+@pytest.mark.parametrize("name", sorted(TABLES))
+def test_huffman_other_tables(oracle, tmp_path, name):
+    """shuffman_* with a caller-supplied table (read_code_table + build_symbol_encoder in the
+    reference's interface): subsequence sizes 32/64/128, bit patterns that are no code, codes of
+    up to 24 bits; multi-tile reads, byte parity with the oracle and lossless both ways"""
+    lens = TABLES[name]
+    assert len(lens) == 256
+    path = str(tmp_path / (name + ".huffman"))
+    _write_table(path, lens, _canonical_table(lens))
+    rng = np.random.default_rng(len(name))
+    try:
+        oracle.load_table(path)
+        press.use_table(path)
+        for n, spread in ((1, 3), (2, 3), (9, 200), (5000, 3), (70000, 90), (150001, 127)):
+            # random walk: zig-zag deltas cover [0, 2*spread]; a few exceptions sprinkled in
+            steps = rng.integers(-spread, spread + 1, size=n)
+            steps[rng.random(n) < 0.01] += 400
+            sig = np.cumsum(steps).astype(np.int16)
+            for m in ("shuffman_vbe21_zd", "shuffman_vbsse21_zd"):
+                if shuff_ok(m, sig):
+                    check_read(oracle, m, sig)
+    finally:
+        oracle.load_table()
+        press.use_table()
+
+
+def test_huffman_truncated_payload(oracle):
+    """a Huffman stream cut short anywhere (tile boundaries included): the decoder delivers what
+    the reference's huffman_decode_memory would - it stops when the bytes run out - and never
+    writes past the caller's buffer"""
+    sig, off = synth.synth_batch(21, 0, 3)
+    sig = sig[int(off[0]):int(off[1])][:150000]
+    m = "shuffman_vbe21_zd"
+    ret, full = oracle.press(m, sig)
+    assert ret == 0
+    n = sig.size
+    for cut in (len(full) - 1, len(full) - 2, len(full) - 4000, 8192 + 600, 8192 * 3 + 9, 700, 20):
+        part = full[:cut]
+        ro, bo = oracle.depress(m, part, n)
+        rg, bg = press.depress(m, part, n)  # canaries checked inside depress()
+        assert (rg == 0) == (ro == 0), (cut, rg, ro)
+        if ro == 0:
+            assert bg.size == bo.size and np.array_equal(bg, bo), (cut, bg.size, bo.size)
