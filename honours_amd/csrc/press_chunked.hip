@@ -1523,17 +1523,44 @@ __device__ __forceinline__ uint32_t lower_bound_dev(const uint32_t *p, uint32_t 
 	return lo;
 }
 
-// slow path of one sub-tile: values of the lane's 8 samples, exceptions merged in
+// Exceptions in front of every wave quarter of every chunk (ChunkDesc::ebefore / ecnt): five
+// binary searches of the read's sorted position list per chunk, one lane each - here they
+// run a hundred thousand at a time instead of in front of the data loads of
+// k_low_decode_chunked (22 dependent round trips per wave).
+__global__ __launch_bounds__(256) void k_ex_ranks(DecodeArgs a)
+{
+	const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+	const uint32_t c = g >> 3, l = g & 7u;
+	uint32_t b = 0;
+	const bool act = c < a.ctl->nchunks && c < a.max_chunks;
+	if (act && l < 5) {
+		const ChunkDesc *dp = a.chunks + c;
+		const uint32_t n = dp->n;
+		const uint32_t ws = dp->j * CHUNK + l * WAVE_SAMPLES; // l = 4: the end of the chunk
+		const uint32_t upto = ws < n ? ws : n;                // exceptions among samples [1, upto)
+		b = lower_bound_dev(a.ex_pos + dp->sig_off, a.meta[dp->read].nex, upto ? upto - 1 : 0);
+	}
+	const uint32_t nxt = (uint32_t) __shfl_down((int) b, 1, 64);
+	if (act && l < 4) {
+		ChunkDesc *dp = a.chunks + c;
+		dp->ecnt[l] = nxt - b;
+		if (l == 0)
+			dp->ebefore = b;
+	}
+}
+
+// slow path of one sub-tile: values of the lane's 8 samples, exceptions merged in.  The
+// exceptions of the sub-tile are pos[e_first, e_first + e_cnt): the search stays inside them.
 __device__ __forceinline__ void gather_low(const uint8_t *low, uint32_t nlow, const uint32_t *pos,
 					   const uint32_t *val, uint32_t nex, uint32_t zd0, uint32_t i0,
-					   uint32_t n, uint32_t v[4])
+					   uint32_t n, uint32_t e_first, uint32_t e_cnt, uint32_t v[4])
 {
 	v[0] = v[1] = v[2] = v[3] = 0;
 	if (i0 >= n)
 		return;
 	const uint32_t nv = min(8u, n - i0);
 	const uint32_t uf = i0 ? i0 - 1 : 0;
-	uint32_t e = lower_bound_dev(pos, nex, uf);
+	uint32_t e = e_first + lower_bound_dev(pos + e_first, e_cnt, uf);
 	uint32_t l = uf - e; // index of the next one-byte value
 	uint32_t nextpos = e < nex ? pos[e] : 0xFFFFFFFFu;
 #pragma unroll
@@ -1594,12 +1621,14 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 	const uint32_t nsub = ws >= n ? 0u : min((uint32_t) CK, (n - ws + SUB - 1) / SUB);
 	const uint32_t live = (1u << nsub) - 1u;
 
-	// ---- exceptions of this wave's quarter: which sub-tiles hold one, how many before each
-	uint32_t e_lo = 0;
+	// ---- exceptions of this wave's quarter (ranks from k_ex_ranks): which sub-tiles hold one,
+	// how many before each
+	const ChunkDesc *dp = a.chunks + t;
+	const uint32_t c0 = uni(dp->ecnt[0]), c1 = uni(dp->ecnt[1]), c2 = uni(dp->ecnt[2]), c3 = uni(dp->ecnt[3]);
+	const uint32_t ew = w == 0 ? c0 : w == 1 ? c1 : w == 2 ? c2 : c3;
+	const uint32_t e_lo = (uint32_t) uni64(dp->ebefore) + (w > 0 ? c0 : 0u) + (w > 1 ? c1 : 0u) + (w > 2 ? c2 : 0u);
 	if (nsub) {
-		const uint32_t wend = min(ws + WAVE_SAMPLES, n);
-		e_lo = lower_bound_dev(pos, nex, ws ? ws - 1 : 0);
-		const uint32_t e_hi = lower_bound_dev(pos, nex, wend - 1);
+		const uint32_t e_hi = e_lo + ew;
 		for (uint32_t e = e_lo + lane; e < e_hi; e += 64) {
 			const uint32_t k = (pos[e] + 1 - ws) / SUB;
 			atomicAdd(&s_cnt[w][k], 1u);
@@ -1660,7 +1689,9 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 	for (uint32_t mm = kmask; mm; mm &= mm - 1) {
 		const uint32_t k = (uint32_t) __builtin_ctz(mm);
 		uint32_t v[4];
-		gather_low(low, nlow, pos, val, nex, zd0, ws + k * SUB + lane * 8, n, v);
+		const uint32_t ef = uni(s_cnt[w][k]);
+		const uint32_t ec = (k + 1 < (uint32_t) CK ? uni(s_cnt[w][k + 1 < (uint32_t) CK ? k + 1 : k]) : ew) - ef;
+		gather_low(low, nlow, pos, val, nex, zd0, ws + k * SUB + lane * 8, n, e_lo + ef, ec, v);
 		uint32_t acc = 0;
 #pragma unroll
 		for (int h = 0; h < 4; h++)
@@ -1727,7 +1758,9 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 		const uint32_t k = (uint32_t) __builtin_ctz(mm);
 		const uint32_t i0 = ws + k * SUB + lane * 8;
 		uint32_t v[4];
-		gather_low(low, nlow, pos, val, nex, zd0, i0, n, v);
+		const uint32_t ef = uni(s_cnt[w][k]);
+		const uint32_t ec = (k + 1 < (uint32_t) CK ? uni(s_cnt[w][k + 1 < (uint32_t) CK ? k + 1 : k]) : ew) - ef;
+		gather_low(low, nlow, pos, val, nex, zd0, i0, n, e_lo + ef, ec, v);
 #pragma unroll
 		for (int h = 0; h < 4; h++)
 			v[h] = unzz_pair(v[h]);
@@ -1830,6 +1863,7 @@ void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, bool huff, hipStream
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL(k_chunk_prep_meta, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off, a.in_off,
 			   a.meta, a.nreads, a.chunks, a.gran, a.ctl, a.max_chunks, a.out_n);
+	hipLaunchKernelGGL(k_ex_ranks, dim3((a.max_chunks * 8 + 255) / 256), dim3(256), 0, s, a);
 	if (!huff)
 		ktime_begin(1, s);
 	if (huff)
