@@ -156,7 +156,7 @@ uint64_t bound_vb1e2(uint32_t m) { return (uint64_t) (1 + m * 0.2 * 6 + m * 0.8)
 uint64_t bound_vbzd(uint32_t n) { return 2 + bound_vb1e2(n - 1); }                             // press.c:3411
 
 bool is_shuff(int m) { return m >= PRESS_HIP_SHUFF_VBE21_ZD && m <= PRESS_HIP_SHUFF_VBSSE21_ZD; }
-bool is_svb(int m) { return m == PRESS_HIP_SVB12 || m == PRESS_HIP_SVB12_ZD || m == PRESS_HIP_SVB_ZD; }
+bool is_svb(int m) { return m == PRESS_HIP_SVB12 || m == PRESS_HIP_SVB12_ZD || m == PRESS_HIP_SVB_ZD || m == PRESS_HIP_SLOW5_SVB_ZD; }
 bool is_zstd(int m)
 {
 	return m == PRESS_HIP_ZSTD_SVB_ZD || m == PRESS_HIP_ZSTD_SVB12_ZD || m == PRESS_HIP_ZSTD_HASGAM_ZDQ;
@@ -494,6 +494,7 @@ extern "C" uint64_t press_hip_bound(int method, uint32_t n)
 	case PRESS_HIP_ZSTD_SVB12_ZD:   return zstd_bound_(4 + bound_svb16(n));         // press.c:2020
 	case PRESS_HIP_HASGAM_ZDQ:      return bound_svb32((uint32_t) bound_vbzd(n));   // press.c:8461
 	case PRESS_HIP_ZSTD_HASGAM_ZDQ: return zstd_bound_(bound_svb32((uint32_t) bound_vbzd(n)));
+	case PRESS_HIP_SLOW5_SVB_ZD:    return (uint64_t) (n + 3) / 4 + (uint64_t) n * 4 + 4; // slow5_press.c:1037 (streamvbyte.h:31) + u32 count
 	default:
 		if (is_ex(method))
 			return bound_vbzd(n);                                           // press.c:3411,4409
@@ -520,6 +521,7 @@ static int launch_press(int method, const BatchArgs &a, hipStream_t s)
 	case PRESS_HIP_SVB12:    v1 ? launch_svb_encode(a, false, false, s) : launch_svb_encode_chunked(a, false, false, s); break;
 	case PRESS_HIP_SVB12_ZD: v1 ? launch_svb_encode(a, false, true, s) : launch_svb_encode_chunked(a, false, true, s); break;
 	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_encode(a, true, true, s) : launch_svb_encode_chunked(a, true, true, s); break;
+	case PRESS_HIP_SLOW5_SVB_ZD: launch_svb_encode_chunked(a, true, true, s, true); break;
 	default:
 		v1 ? launch_ex_encode(a, exfmt_of(method), is_shuff(method), s)
 		   : launch_ex_encode_chunked(a, exfmt_of(method), is_shuff(method), s);
@@ -537,6 +539,7 @@ static int launch_depress(int method, const DecodeArgs &a, hipStream_t s)
 	case PRESS_HIP_SVB12:    v1 ? launch_svb_decode(a, false, false, s) : launch_svb_decode_chunked(a, false, false, s); break;
 	case PRESS_HIP_SVB12_ZD: v1 ? launch_svb_decode(a, false, true, s) : launch_svb_decode_chunked(a, false, true, s); break;
 	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_decode(a, true, true, s) : launch_svb_decode_chunked(a, true, true, s); break;
+	case PRESS_HIP_SLOW5_SVB_ZD: launch_svb_decode_chunked(a, true, true, s, true); break;
 	default:
 		v1 ? launch_ex_decode(a, exfmt_of(method), is_shuff(method), s)
 		   : launch_ex_decode_chunked(a, exfmt_of(method), is_shuff(method), s);
@@ -1182,6 +1185,66 @@ int zstd_hasgam_vbsse21_zdq_press_16(const int16_t *in, uint32_t nin, uint8_t *o
 int zstd_hasgam_vbsse21_zdq_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout)
 {
 	return zstd_depress_(PRESS_HIP_HASGAM_ZDQ, false, in, nin, out, nout);
+}
+
+// ---- BLOW5's signal codec "svb-zd" (slow5lib slow5_press.c:1054,1110), SURVEY 8f-2
+uint64_t slow5_svb_zd_bound(uint32_t nin) { return press_hip_bound(PRESS_HIP_SLOW5_SVB_ZD, nin); }
+int slow5_svb_zd_press(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout)
+{
+	if (nin == 0) { // an empty signal is just its count
+		if (*nout < 4)
+			return -1;
+		memset(out, 0, 4);
+		*nout = 4;
+		return 0;
+	}
+	return int_press_inner(PRESS_HIP_SLOW5_SVB_ZD, in, nin, out, nout);
+}
+int slow5_svb_zd_depress(const uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout)
+{
+	uint32_t cnt, n = 0;
+	if (nin < 4)
+		return -1;
+	memcpy(&cnt, in, 4); // slow5_press.c:1086: the count travels in the stream
+	if (cnt > *nout)
+		return -1;
+	if (cnt == 0) {
+		*nout = 0;
+		return nin == 4 ? 0 : -1;
+	}
+	if (depress_one(PRESS_HIP_SLOW5_SVB_ZD, in, nin, out, cnt, &n))
+		return -1;
+	*nout = n;
+	return 0;
+}
+// the shape slow5lib itself uses (slow5_ptr_compress_solo / slow5_ptr_depress_solo with
+// SLOW5_COMPRESS_SVB_ZD, slow5_press.h:103-105): malloc'd result, byte counts in and out
+void *press_hip_slow5_ptr_compress_svb_zd(const int16_t *ptr, size_t count, size_t *n)
+{
+	const uint32_t ns = (uint32_t) (count / sizeof *ptr);
+	uint64_t len = slow5_svb_zd_bound(ns);
+	uint8_t *out = (uint8_t *) malloc(len + 16);
+	if (!out || slow5_svb_zd_press(ptr, ns, out, &len)) {
+		free(out);
+		return nullptr;
+	}
+	*n = (size_t) len;
+	return out;
+}
+void *press_hip_slow5_ptr_depress_svb_zd(const uint8_t *ptr, size_t count, size_t *n)
+{
+	uint32_t cnt;
+	if (count < 4)
+		return nullptr;
+	memcpy(&cnt, ptr, 4);
+	int16_t *out = (int16_t *) malloc(((size_t) cnt + 8) * sizeof *out);
+	uint32_t got = cnt;
+	if (!out || slow5_svb_zd_depress(ptr, count, out, &got)) {
+		free(out);
+		return nullptr;
+	}
+	*n = (size_t) got * sizeof *out;
+	return out;
 }
 
 } // extern "C"

@@ -80,6 +80,19 @@ __device__ __forceinline__ uint32_t zd_pair(uint32_t cur, uint32_t prevdw)
 	return __builtin_bit_cast(uint32_t, z);
 }
 
+// the same, and which of the two differences do not fit 16 bits (bit 15 / bit 31 of `ov`): slow5lib
+// takes the delta in 32 bits (streamvbyte_zigzag.c:15), so such a value is 17 bits wide.
+// If d16 is the wrapped difference and z16 its zig-zag, the true zig-zag is (~z16 & 0xFFFF) | 0x10000.
+__device__ __forceinline__ uint32_t zd_pair_ovf(uint32_t cur, uint32_t prevdw, uint32_t &ov)
+{
+	const uint32_t sh = __builtin_amdgcn_alignbit(cur, prevdw, 16); // [prev.hi, cur.lo]
+	const s16x2 d = __builtin_bit_cast(s16x2, cur) - __builtin_bit_cast(s16x2, sh);
+	const uint32_t du = __builtin_bit_cast(uint32_t, d);
+	ov |= (cur ^ sh) & (cur ^ du) & 0x80008000u; // a - b overflows iff sign(a) != sign(b) and sign(a - b) != sign(a)
+	const s16x2 z = (d << 1) ^ (d >> 15);
+	return __builtin_bit_cast(uint32_t, z);
+}
+
 // relaxed agent-scope granule access (sc1: L2-coherent, bypasses this CU's L1)
 __device__ __forceinline__ void gran_store(uint64_t *g, uint64_t v)
 {
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 						    uint32_t nreads, ChunkDesc *chunks, uint64_t *gran,
 						    ChunkCtl *ctl, uint32_t max_chunks, uint64_t *out_len,
 						    uint32_t *out_n, uint32_t *first_chunk, ReadMeta *meta = nullptr,
-						    uint64_t *gran2 = nullptr)
+						    uint64_t *gran2 = nullptr, const uint8_t *in = nullptr, uint32_t hdr = 0)
 {
 	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
 	uint32_t n = 0, nch = 0;
@@ -198,11 +211,17 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 	}
 	const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
 	const uint64_t sbase = slot_off[r];
+	// hdr = 4: the slow5 svb-zd stream (u32 sample count in front, values of up to 3 bytes)
 	uint32_t ok;
-	if (!DEC)
-		ok = (uint64_t) klen + 2ull * n <= slot_off[r + 1] - sbase;
-	else
-		ok = klen <= in_len[r];
+	if (!DEC) {
+		ok = (uint64_t) hdr + klen + (hdr ? 3ull : 2ull) * n <= slot_off[r + 1] - sbase;
+	} else {
+		ok = (uint64_t) hdr + klen <= in_len[r];
+		if (ok && hdr) { // slow5_press.c:1086: the count in the stream is what gets decoded
+			const uint8_t *h = in + sbase;
+			ok = ((uint32_t) h[0] | ((uint32_t) h[1] << 8) | ((uint32_t) h[2] << 16) | ((uint32_t) h[3] << 24)) == n;
+		}
+	}
 	if (n == 0) {
 		if (!DEC)
 			out_len[r] = 0;
@@ -234,9 +253,12 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 
 // ------------------------------------------------------------------ encode
 
-template <bool KEY2, bool ZD>
+// S5 (with KEY2, ZD): slow5lib's "svb-zd" signal codec (slow5_press.c:1054): a u32 sample count
+// in front, and the delta taken in 32 bits - a jump of more than 32767 is a 3-byte value.
+template <bool KEY2, bool ZD, bool S5 = false>
 __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 {
+	static_assert(!S5 || (KEY2 && ZD), "the slow5 variant is svb32 of zig-zag deltas");
 	__shared__ uint32_t s_ticket;
 	__shared__ uint32_t s_wtot[4];
 	__shared__ uint64_t s_excl;
@@ -269,7 +291,14 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 	}
 
 	const int16_t *in = a.sig + d.sig_off;
-	uint8_t *out = a.out + d.out_base;
+	uint8_t *out = a.out + d.out_base + (S5 ? 4 : 0);
+	if (S5 && first == 0 && threadIdx.x == 0) { // slow5_press.c:1046: the sample count
+		uint8_t *h = a.out + d.out_base;
+		h[0] = (uint8_t) n;
+		h[1] = (uint8_t) (n >> 8);
+		h[2] = (uint8_t) (n >> 16);
+		h[3] = (uint8_t) (n >> 24);
+	}
 	const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
 	const uint32_t ws = first + w * WAVE_SAMPLES; // first sample of this wave's quarter
 
@@ -287,17 +316,27 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 		carry = (uint32_t) (uint16_t) in[ws - 1] << 16;
 
 	uint32_t kmask = 0;  // sub-tiles that need the slow path (exceptions or a ragged tail)
+	uint32_t omask = 0;  // S5: sub-tiles with a 17-bit value
 	uint32_t etot = 0;   // exceptions in this wave's quarter (uniform)
 #pragma unroll
 	for (int k = 0; k < CK; k++) {
 		const uint32_t i0 = ws + k * SUB + lane * 8;
 		const uint32_t raw_w = z[k].w;
+		uint32_t ov[4] = { 0, 0, 0, 0 };
 		if (ZD) {
 			const uint32_t pw = prev_lane(raw_w, carry);
-			const uint32_t z0 = zd_pair(z[k].x, pw);
-			const uint32_t z1 = zd_pair(z[k].y, z[k].x);
-			const uint32_t z2 = zd_pair(z[k].z, z[k].y);
-			const uint32_t z3 = zd_pair(z[k].w, z[k].z);
+			uint32_t z0, z1, z2, z3;
+			if (S5) {
+				z0 = zd_pair_ovf(z[k].x, pw, ov[0]);
+				z1 = zd_pair_ovf(z[k].y, z[k].x, ov[1]);
+				z2 = zd_pair_ovf(z[k].z, z[k].y, ov[2]);
+				z3 = zd_pair_ovf(z[k].w, z[k].z, ov[3]);
+			} else {
+				z0 = zd_pair(z[k].x, pw);
+				z1 = zd_pair(z[k].y, z[k].x);
+				z2 = zd_pair(z[k].z, z[k].y);
+				z3 = zd_pair(z[k].w, z[k].z);
+			}
 			z[k] = make_uint4(z0, z1, z2, z3);
 			carry = (uint32_t) __builtin_amdgcn_readlane((int) raw_w, 63);
 		}
@@ -313,20 +352,36 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 					zz[q] &= 0xFFFFu;
 			}
 			z[k] = make_uint4(zz[0], zz[1], zz[2], zz[3]);
+			if (S5) { // ... and their differences cannot overflow
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					if (nv <= (uint32_t) (2 * q))
+						ov[q] = 0;
+					else if (nv == (uint32_t) (2 * q + 1))
+						ov[q] &= 0xFFFFu;
+				}
+			}
 		}
 		const uint32_t hi = (z[k].x | z[k].y | z[k].z | z[k].w) & 0xFF00FF00u;
 		const bool ragged = i0 < n && i0 + 8 > n;
-		const unsigned long long bx = __ballot(hi != 0);
+		const unsigned long long bo = S5 ? __ballot((ov[0] | ov[1] | ov[2] | ov[3]) != 0) : 0ull;
+		const unsigned long long bx = __ballot(hi != 0) | bo;
 		const unsigned long long br = __ballot(ragged);
 		if (bx | br)
 			kmask |= 1u << k;
+		if (bo)
+			omask |= 1u << k;
 		if (bx) {
-			// exact count: one popcount of a ballot per key bit
+			// exact count of the extra bytes: one popcount of a ballot per key bit; a 17-bit
+			// value has two of them whatever its low half looks like
 			const uint32_t zz[4] = { z[k].x, z[k].y, z[k].z, z[k].w };
 #pragma unroll
 			for (int q = 0; q < 4; q++) {
-				etot += (uint32_t) __popcll(__ballot((zz[q] & 0x0000FF00u) != 0));
-				etot += (uint32_t) __popcll(__ballot((zz[q] & 0xFF000000u) != 0));
+				const bool o0 = S5 && (ov[q] & 0x00008000u), o1 = S5 && (ov[q] & 0x80000000u);
+				etot += (uint32_t) __popcll(__ballot(!o0 && (zz[q] & 0x0000FF00u) != 0));
+				etot += (uint32_t) __popcll(__ballot(!o1 && (zz[q] & 0xFF000000u) != 0));
+				if (S5 && bo)
+					etot += 2u * (uint32_t) (__popcll(__ballot(o0)) + __popcll(__ballot(o1)));
 			}
 		}
 	}
@@ -345,7 +400,7 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 	const uint64_t ebefore = uni64(s_excl);
 	uint64_t ebase = ebefore + (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
 	if (last && threadIdx.x == 0)
-		a.out_len[d.read] = (uint64_t) klen + n + ebefore + t0 + t1 + t2 + t3;
+		a.out_len[d.read] = (uint64_t) (S5 ? 4 : 0) + klen + n + ebefore + t0 + t1 + t2 + t3;
 
 	// ---- phase 2: keys and data
 	uint8_t *data = out + klen;
@@ -380,7 +435,24 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 			key |= ((zz[q] & 0xFF000000u) ? 1u : 0u) << (2 * q + 1);
 		}
 		const uint32_t nv = i0 < n ? min(8u, n - i0) : 0u;
-		const uint32_t cnt = __popc(key);
+		uint32_t wide = 0; // S5: which of the lane's values are 17 bits wide (from the samples again: rare)
+		if (S5 && ((omask >> k) & 1u) && nv) {
+			const uint4 raw = *reinterpret_cast<const uint4 *>(in + i0);
+			const uint32_t pv = i0 ? (uint32_t) (uint16_t) in[i0 - 1] << 16 : 0u;
+			uint32_t ov[4] = { 0, 0, 0, 0 };
+			(void) zd_pair_ovf(raw.x, pv, ov[0]);
+			(void) zd_pair_ovf(raw.y, raw.x, ov[1]);
+			(void) zd_pair_ovf(raw.z, raw.y, ov[2]);
+			(void) zd_pair_ovf(raw.w, raw.z, ov[3]);
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				wide |= ((ov[q] >> 15) & 1u) << (2 * q);
+				wide |= ((ov[q] >> 31) & 1u) << (2 * q + 1);
+			}
+			wide &= (1u << nv) - 1u;
+			key &= ~wide;
+		}
+		const uint32_t cnt = __popc(key) + 2u * __popc(wide);
 		const uint32_t inc = wave_incl_scan32(cnt);
 		const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
 		uint8_t *p = data + ebase + i0 + (inc - cnt);
@@ -391,8 +463,8 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 				uint32_t k0 = 0, k1 = 0;
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
-					k0 |= ((key >> q) & 1u) << (2 * q);
-					k1 |= ((key >> (q + 4)) & 1u) << (2 * q);
+					k0 |= (((key >> q) & 1u) | (((wide >> q) & 1u) << 1)) << (2 * q);
+					k1 |= (((key >> (q + 4)) & 1u) | (((wide >> (q + 4)) & 1u) << 1)) << (2 * q);
 				}
 				out[i0 >> 2] = (uint8_t) k0;
 				if (nv > 4)
@@ -407,10 +479,14 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 #pragma unroll
 				for (int q = 0; q < 8; q++) {
 					if ((uint32_t) q < nv) {
-						const uint32_t val = (zz[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+						uint32_t val = (zz[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+						if (S5 && ((wide >> q) & 1u))
+							val = (~val & 0xFFFFu) | 0x10000u;
 						*p++ = (uint8_t) val;
 						if (val > 255u)
 							*p++ = (uint8_t) (val >> 8);
+						if (val > 65535u)
+							*p++ = (uint8_t) (val >> 16);
 					}
 				}
 			}
@@ -509,10 +585,12 @@ __device__ __forceinline__ uint32_t key_extra_bytes(uint32_t kk)
 // Slow path of one sub-tile (exceptions, a ragged tail, or the end of the stream is near):
 // byte-wise, bounds-checked gather of the lane's values into packed 16-bit pairs.
 // `eb` = exceptions in front of the sub-tile; returns the sub-tile's exception count.
-template <bool KEY2>
+// S5: values may be 17 bits wide (slow5lib); bit q of `hib` = bit 16 of the lane's value q.
+template <bool KEY2, bool S5 = false>
 __device__ __forceinline__ uint32_t gather_slow(const uint8_t *in, const uint8_t *data, uint64_t dlen,
-						uint32_t i0, uint32_t n, uint64_t eb, uint32_t v[4])
+						uint32_t i0, uint32_t n, uint64_t eb, uint32_t v[4], uint32_t &hib)
 {
+	hib = 0;
 	const uint32_t kk = load_key<KEY2>(in, i0, n);
 	const uint32_t c = key_extra_bytes<KEY2>(kk);
 	const uint32_t inc = wave_incl_scan_dpp(c);
@@ -527,11 +605,19 @@ __device__ __forceinline__ uint32_t gather_slow(const uint8_t *in, const uint8_t
 			uint32_t val = p < dlen ? data[p] : 0u;
 			if (code >= 1)
 				val |= (p + 1 < dlen ? (uint32_t) data[p + 1] : 0u) << 8;
+			if (S5 && code >= 2)
+				hib |= (p + 2 < dlen ? (uint32_t) data[p + 2] & 1u : 0u) << q;
 			p += 1 + code;
 			v[q >> 1] |= val << (16 * (q & 1));
 		}
 	}
 	return tot;
+}
+
+// inverse zig-zag of pair q of a gathered lane; a value's bit 16 ends up in bit 15 of z >> 1
+__device__ __forceinline__ uint32_t unzz_pair_hib(uint32_t z, uint32_t hib, int q)
+{
+	return unzz_pair(z) ^ ((((hib >> (2 * q)) & 1u) << 15) | (((hib >> (2 * q + 1)) & 1u) << 31));
 }
 
 // 8 one-byte values -> 4 packed pairs
@@ -551,7 +637,7 @@ __device__ __forceinline__ void expand8(uint2 dd, uint32_t v[4])
 // extra data bytes (exceptions) the quarter holds.  A wave quarter's key bytes are contiguous
 // (1 KiB for svb16, 2 KiB for svb32): each lane takes 16 of them with one (unaligned) 16-byte
 // load, the count is one popcount reduction and the per-sub-tile flags come from one ballot.
-template <bool KEY2>
+template <bool KEY2, bool S5 = false>
 __global__ __launch_bounds__(CWG) void k_svb_keyscan(DecodeArgs a)
 {
 	const uint32_t c = blockIdx.x;
@@ -561,8 +647,8 @@ __global__ __launch_bounds__(CWG) void k_svb_keyscan(DecodeArgs a)
 	if (!uni(dp->cap_ok))
 		return;
 	const uint32_t n = uni(dp->n);
-	const uint8_t *in = a.in + uni64(dp->out_base);
-	const uint64_t in_len = uni64(a.in_len[uni(dp->read)]);
+	const uint8_t *in = a.in + uni64(dp->out_base) + (S5 ? 4 : 0);
+	const uint64_t in_len = uni64(a.in_len[uni(dp->read)]) - (S5 ? 4 : 0);
 	const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
 	const int lane = threadIdx.x & 63;
 	const int w = (int) uni(threadIdx.x >> 6);
@@ -627,7 +713,7 @@ __global__ __launch_bounds__(CWG) void k_svb_keyscan(DecodeArgs a)
 	uint64_t etot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
 	// 3- and 4-byte codes cannot come from a 16-bit signal: poison the count so that the
 	// read fails its length check and its offsets fall out of range
-	if (KEY2 && __ballot(bad != 0))
+	if (KEY2 && !S5 && __ballot(bad != 0))
 		etot += 1u << 30;
 	if (lane == 0) {
 		dp->ecnt[w] = (uint32_t) (etot > 0xFFFFFFFFull ? 0xFFFFFFFFull : etot);
@@ -637,7 +723,7 @@ __global__ __launch_bounds__(CWG) void k_svb_keyscan(DecodeArgs a)
 
 // One thread per read: exclusive prefix of the chunk counts, and the verdict on the stream
 // length (decode.hpp:23 consumes klen + n + #exceptions bytes).
-template <bool KEY2>
+template <bool KEY2, bool S5 = false>
 __global__ __launch_bounds__(256) void k_svb_keyprefix(DecodeArgs a)
 {
 	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
@@ -647,19 +733,20 @@ __global__ __launch_bounds__(256) void k_svb_keyprefix(DecodeArgs a)
 	if (n == 0)
 		return; // out_n[r] = 0 written by k_chunk_prep
 	const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
-	const uint64_t in_len = a.in_len[r];
-	if (klen > in_len) {
+	const uint64_t in_len = a.in_len[r] - (S5 ? 4 : 0);
+	ChunkDesc *dp = a.chunks + a.first_chunk[r];
+	if (a.in_len[r] < (S5 ? 4u : 0u) || klen > in_len || !dp->cap_ok) { // cap_ok: k_chunk_prep (S5: the count in the stream)
 		a.out_n[r] = CFAIL32;
 		return;
 	}
-	ChunkDesc *dp = a.chunks + a.first_chunk[r];
 	const uint32_t nch = (n + CHUNK - 1) / CHUNK;
 	uint64_t e = 0;
 	for (uint32_t j = 0; j < nch; j++) {
 		dp[j].ebefore = e;
 		e += (uint64_t) dp[j].ecnt[0] + dp[j].ecnt[1] + dp[j].ecnt[2] + dp[j].ecnt[3];
 	}
-	a.out_n[r] = ((uint64_t) klen + n + e <= in_len) ? n : CFAIL32;
+	// slow5_press.c:1098: the decoder must consume exactly the bytes it was given
+	a.out_n[r] = (S5 ? (uint64_t) klen + n + e == in_len : (uint64_t) klen + n + e <= in_len) ? n : CFAIL32;
 }
 
 #ifdef DEC_STAMPS
@@ -695,7 +782,7 @@ __device__ __forceinline__ void wave_lds_sync()
 //     (byte-wise gather, one copy of the code);
 //   * both write their per-lane and per-sub-tile running sums to a small wave-private LDS
 //     table, which also frees the registers a per-sub-tile array would take.
-template <bool KEY2, bool ZD>
+template <bool KEY2, bool ZD, bool S5 = false>
 __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 {
 #ifdef DEC_STAMPS
@@ -731,8 +818,8 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 			(void) lookback(a.gran, t, d.j, 0, last);
 		return;
 	}
-	const uint8_t *in = a.in + d.out_base;
-	const uint64_t in_len = uni64(a.in_len[d.read]);
+	const uint8_t *in = a.in + d.out_base + (S5 ? 4 : 0);
+	const uint64_t in_len = uni64(a.in_len[d.read]) - (S5 ? 4 : 0);
 	int16_t *out = a.sig + d.sig_off;
 	const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
 	const uint64_t dlen = in_len - klen; // bytes in the data section (cap_ok: klen <= in_len)
@@ -807,12 +894,12 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 		for (uint32_t m = kmask; m; m &= m - 1) {
 			const uint32_t k = (uint32_t) __builtin_ctz(m);
 			const uint32_t i0 = ws + k * SUB + lane * 8;
-			uint32_t v[4];
-			(void) gather_slow<KEY2>(in, data, dlen, i0, n, ebase + uni(s_epre[w][k]), v);
+			uint32_t v[4], hib;
+			(void) gather_slow<KEY2, S5>(in, data, dlen, i0, n, ebase + uni(s_epre[w][k]), v, hib);
 			uint32_t acc = 0;
 #pragma unroll
 			for (int q = 0; q < 4; q++)
-				acc = pk_add16(acc, unzz_pair(v[q]));
+				acc = pk_add16(acc, unzz_pair_hib(v[q], hib, q));
 			const uint32_t tot16 = (acc + (acc >> 16)) & 0xFFFFu;
 			const uint32_t inc = wave_incl_scan_dpp(tot16);
 			s_xl[w][k][lane] = (uint16_t) (inc - tot16);
@@ -886,12 +973,12 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 	for (uint32_t m = kmask; m; m &= m - 1) {
 		const uint32_t k = (uint32_t) __builtin_ctz(m);
 		const uint32_t i0 = ws + k * SUB + lane * 8;
-		uint32_t v[4];
-		(void) gather_slow<KEY2>(in, data, dlen, i0, n, ebase + uni(s_epre[w][k]), v);
+		uint32_t v[4], hib;
+		(void) gather_slow<KEY2, S5>(in, data, dlen, i0, n, ebase + uni(s_epre[w][k]), v, hib);
 		if (ZD) {
 #pragma unroll
 			for (int q = 0; q < 4; q++)
-				v[q] = unzz_pair(v[q]);
+				v[q] = unzz_pair_hib(v[q], hib, q);
 			(void) lane_prefix8(v);
 			const uint32_t b16 = (sb + uni(s_sub[w][k]) + s_xl[w][k][lane]) & 0xFFFFu;
 			const uint32_t b2 = b16 | (b16 << 16);
@@ -1786,25 +1873,28 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 
 // ------------------------------------------------------------------ launchers
 
-template <bool KEY2, bool ZD>
+template <bool KEY2, bool ZD, bool S5 = false>
 static void run_encode(const BatchArgs &a, hipStream_t s)
 {
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL((k_chunk_prep<false, KEY2>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
 			   a.nsamp, a.out_off, (const uint64_t *) nullptr, a.nreads, a.chunks, a.gran, a.ctl,
-			   a.max_chunks, a.out_len, (uint32_t *) nullptr, (uint32_t *) nullptr);
+			   a.max_chunks, a.out_len, (uint32_t *) nullptr, (uint32_t *) nullptr, (ReadMeta *) nullptr,
+			   (uint64_t *) nullptr, (const uint8_t *) nullptr, S5 ? 4u : 0u);
 	// persistent grid: enough workgroups to fill the chip twice over (4 resident per CU)
 	const uint32_t grid = a.max_chunks < PERSISTENT_GRID ? a.max_chunks : PERSISTENT_GRID;
 	ktime_begin(0, s);
-	hipLaunchKernelGGL((k_svb_encode_chunked<KEY2, ZD>), dim3(grid), dim3(CWG), 0, s, a);
+	hipLaunchKernelGGL((k_svb_encode_chunked<KEY2, ZD, S5>), dim3(grid), dim3(CWG), 0, s, a);
 	ktime_end(0, s);
 }
 
-void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s)
+void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s, bool slow5)
 {
 	if (!a.nreads || !a.max_chunks)
 		return;
-	if (key2bit)
+	if (slow5)
+		run_encode<true, true, true>(a, s);
+	else if (key2bit)
 		run_encode<true, true>(a, s);
 	else if (zd)
 		run_encode<false, true>(a, s);
@@ -1812,18 +1902,19 @@ void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStr
 		run_encode<false, false>(a, s);
 }
 
-template <bool KEY2, bool ZD>
+template <bool KEY2, bool ZD, bool S5 = false>
 static void run_decode(const DecodeArgs &a, hipStream_t s)
 {
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL((k_chunk_prep<true, KEY2>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
 			   a.nsamp, a.in_off, a.in_len, a.nreads, a.chunks, a.gran, a.ctl, a.max_chunks,
-			   (uint64_t *) nullptr, a.out_n, a.first_chunk);
+			   (uint64_t *) nullptr, a.out_n, a.first_chunk, (ReadMeta *) nullptr, (uint64_t *) nullptr, a.in,
+			   S5 ? 4u : 0u);
 	// surplus workgroups (max_chunks bounds the real count from above) exit at once
-	hipLaunchKernelGGL((k_svb_keyscan<KEY2>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
-	hipLaunchKernelGGL((k_svb_keyprefix<KEY2>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a);
+	hipLaunchKernelGGL((k_svb_keyscan<KEY2, S5>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
+	hipLaunchKernelGGL((k_svb_keyprefix<KEY2, S5>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a);
 	ktime_begin(1, s);
-	hipLaunchKernelGGL((k_svb_decode_chunked<KEY2, ZD>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
+	hipLaunchKernelGGL((k_svb_decode_chunked<KEY2, ZD, S5>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	ktime_end(1, s);
 }
 
@@ -1874,11 +1965,13 @@ void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, bool huff, hipStream
 		ktime_end(1, s);
 }
 
-void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s)
+void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s, bool slow5)
 {
 	if (!a.nreads || !a.max_chunks)
 		return;
-	if (key2bit)
+	if (slow5)
+		run_decode<true, true, true>(a, s);
+	else if (key2bit)
 		run_decode<true, true>(a, s);
 	else if (zd)
 		run_decode<false, true>(a, s);

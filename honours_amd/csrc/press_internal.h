@@ -144,8 +144,8 @@ void ktime_end(int which, hipStream_t s);
 
 // launchers (press_kernels.hip).  All asynchronous on `s`.
 void launch_svb_encode(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s);      // v1: one workgroup per read
-void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s); // v2: chunks + look-back
-void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s);
+void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s, bool slow5 = false); // v2: chunks + look-back
+void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s, bool slow5 = false);
 void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_t s);
 void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, bool huff, hipStream_t s);
 void launch_ex_parse_huff(const DecodeArgs &a, int fmt, bool huff, hipStream_t s); // press_kernels.hip

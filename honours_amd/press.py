@@ -23,6 +23,7 @@ METHODS = {
     "vbe21_zd": 5, "vbbe21_zd": 6, "vbsbe21_zd": 7, "vbsse21_zd": 8,
     "shuffman_vbe21_zd": 9, "shuffman_vbbe21_zd": 10, "shuffman_vbsbe21_zd": 11,
     "shuffman_vbsse21_zd": 12, "hasgam_vbsse21_zdq": 13, "zstd_hasgam_vbsse21_zdq": 14,
+    "slow5_svb_zd": 15,
 }
 BATCH_METHODS = [m for m in METHODS if not m.startswith("zstd_")]
 FAILED = (1 << 64) - 1
@@ -55,6 +56,8 @@ _SYMS = {
                            "hasgam_vbsse21_zdq_depress_16", "int"),
     "zstd_hasgam_vbsse21_zdq": ("zstd_hasgam_vbsse21_zdq_bound_16", "zstd_hasgam_vbsse21_zdq_press_16",
                                 "zstd_hasgam_vbsse21_zdq_depress_16", "int"),
+    # BLOW5's signal codec (slow5lib svb-zd)
+    "slow5_svb_zd": ("slow5_svb_zd_bound", "slow5_svb_zd_press", "slow5_svb_zd_depress", "int"),
 }
 
 # every symbol include/press_hip.h declares (checked by tests/test_abi_symbols.py)
@@ -66,6 +69,9 @@ HEADER_SYMBOLS = sorted(set(
      "press_hip_synchronize", "press_hip_load_table_file", "press_hip_set_table", "press_hip_bound",
      "press_hip_press_batch", "press_hip_depress_batch", "press_hip_workspace_bytes",
      "press_hip_kernel_timing", "press_hip_kernel_times",
+     "press_hip_slow5_ptr_compress_svb_zd", "press_hip_slow5_ptr_depress_svb_zd",
+     "press_hip_blow5_open", "press_hip_blow5_close", "press_hip_blow5_methods", "press_hip_blow5_next",
+     "press_hip_blow5_last_error",
      "press_hip_shutdown"]))
 
 
@@ -370,3 +376,51 @@ def kernel_times(which):
     lib.press_hip_kernel_times.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     n = lib.press_hip_kernel_times(which, buf, 128)
     return [buf[i] for i in range(n)]
+
+
+# ---------------------------------------------------------------------------- BLOW5 input (host side)
+
+class Blow5Reader:
+    """press_hip_blow5_*: iterate over a BLOW5 file's signal fields as stored (svb-zd streams for
+    signal method 1) - what depress_batch_host("slow5_svb_zd", ...) / the device batch API decode."""
+
+    ID_LEN = 64
+
+    def __init__(self, path):
+        lib = load_library()
+        lib.press_hip_blow5_last_error.restype = ctypes.c_char_p
+        lib.press_hip_blow5_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+        lib.press_hip_blow5_close.argtypes = [ctypes.c_void_p]
+        lib.press_hip_blow5_methods.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        lib.press_hip_blow5_next.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.POINTER(ctypes.c_uint32)]
+        self._h = ctypes.c_void_p()
+        if lib.press_hip_blow5_open(path.encode(), ctypes.byref(self._h)):
+            raise PressError(lib.press_hip_blow5_last_error().decode())
+        rm, sm = ctypes.c_int(), ctypes.c_int()
+        lib.press_hip_blow5_methods(self._h, ctypes.byref(rm), ctypes.byref(sm))
+        self.record_method, self.signal_method = rm.value, sm.value
+
+    def next_batch(self, max_reads=4096, arena_bytes=1 << 28):
+        """-> list of (read_id, n_samples, signal field bytes); empty at the end of the file"""
+        lib = load_library()
+        arena = np.empty(arena_bytes, dtype=np.uint8)
+        off = np.zeros(max_reads, dtype=np.uint64)
+        ln = np.zeros(max_reads, dtype=np.uint64)
+        ns = np.zeros(max_reads, dtype=np.uint32)
+        ids = ctypes.create_string_buffer(max_reads * self.ID_LEN)
+        got = ctypes.c_uint32()
+        if lib.press_hip_blow5_next(self._h, max_reads, arena.ctypes.data, arena_bytes, off.ctypes.data,
+                                    ln.ctypes.data, ns.ctypes.data, ids, ctypes.byref(got)):
+            raise PressError(lib.press_hip_blow5_last_error().decode())
+        out = []
+        for k in range(got.value):
+            rid = ids.raw[k * self.ID_LEN:(k + 1) * self.ID_LEN].split(b"\0")[0].decode()
+            out.append((rid, int(ns[k]), arena[int(off[k]):int(off[k]) + int(ln[k])].tobytes()))
+        return out
+
+    def close(self):
+        if self._h:
+            load_library().press_hip_blow5_close(self._h)
+            self._h = ctypes.c_void_p()

@@ -136,6 +136,19 @@ uint64_t zstd_hasgam_vbsse21_zdq_bound_16(uint32_t nin);
 int zstd_hasgam_vbsse21_zdq_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
 int zstd_hasgam_vbsse21_zdq_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
 
+/* ---- BLOW5's signal codec "svb-zd" (SURVEY 8f-2): slow5lib slow5_press.c:1054 ptr_compress_svb_zd /
+ * :1110 ptr_depress_svb_zd, reached through slow5_ptr_compress_solo / slow5_ptr_depress_solo
+ * (slow5_press.h:103-105) from slow5_rec_to_mem (slow5.c:3948) and the record parser.
+ * Stream: u32 sample count, then streamvbyte (2-bit keys) of the 32-bit zig-zag deltas - the same
+ * bytes as the pre-zstd buffer of zstd_svb_zd for signals whose jumps fit 16 bits.
+ * press: *nout capacity in / bytes out; depress: *nout room in samples in / samples out. */
+uint64_t slow5_svb_zd_bound(uint32_t nin);
+int slow5_svb_zd_press(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+int slow5_svb_zd_depress(const uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+/* slow5lib's own calling shape: malloc'd result (free() it), counts in bytes; NULL on failure */
+void *press_hip_slow5_ptr_compress_svb_zd(const int16_t *ptr, size_t count, size_t *n);
+void *press_hip_slow5_ptr_depress_svb_zd(const uint8_t *ptr, size_t count, size_t *n);
+
 /* ======================================================================= (2) batch API */
 
 /* method ids (== oracle/press_methods.h); names are the reference's code names */
@@ -155,7 +168,8 @@ enum press_hip_method {
 	PRESS_HIP_SHUFF_VBSSE21_ZD = 12,
 	PRESS_HIP_HASGAM_ZDQ       = 13,
 	PRESS_HIP_ZSTD_HASGAM_ZDQ  = 14, /* per-read API only */
-	PRESS_HIP_NMETHODS         = 15
+	PRESS_HIP_SLOW5_SVB_ZD     = 15, /* BLOW5's signal codec (section 3) */
+	PRESS_HIP_NMETHODS         = 16
 };
 
 #define PRESS_HIP_OK        0
@@ -231,6 +245,28 @@ int press_hip_kernel_times(int which, float *ms, int max);
 
 /* release every device and host resource held by the library */
 void press_hip_shutdown(void);
+
+/* ======================================================================= (3) BLOW5 input (host) */
+
+/*
+ * Reader for BLOW5 files that hands out the signal fields AS STORED: what the
+ * reference's loader decodes on the CPU (slow5_open slow5.h:345, slow5_get_next :446,
+ * slow5_rec.raw_signal :274) goes to the device compressed and is decoded there with
+ * press_hip_depress_batch(PRESS_HIP_SLOW5_SVB_ZD, ...).  Record compression none / zlib / zstd,
+ * signal compression none / svb-zd.  Host code, usable without a GPU.
+ */
+typedef struct press_hip_blow5 press_hip_blow5;
+#define PRESS_HIP_BLOW5_ID_LEN 64 /* bytes per read id handed out (NUL padded) */
+int press_hip_blow5_open(const char *path, press_hip_blow5 **out);
+void press_hip_blow5_close(press_hip_blow5 *f);
+/* record method: 0 none, 1 zlib, 2 zstd; signal method: 0 none (int16 samples), 1 svb-zd */
+int press_hip_blow5_methods(const press_hip_blow5 *f, int *record_method, int *signal_method);
+/* Next batch: up to max_reads signal fields copied back to back into arena (each starts on a
+ * 16-byte boundary), sig_off / sig_len in bytes, n_samples per read, read_ids (may be NULL)
+ * max_reads x PRESS_HIP_BLOW5_ID_LEN chars.  *got = reads delivered; 0 at the end of the file. */
+int press_hip_blow5_next(press_hip_blow5 *f, uint32_t max_reads, uint8_t *arena, uint64_t arena_cap,
+			 uint64_t *sig_off, uint64_t *sig_len, uint32_t *n_samples, char *read_ids, uint32_t *got);
+const char *press_hip_blow5_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,8 @@ enum press_method {
 	PM_SHUFF_VBSSE21_ZD = 12, /* press.h:658-662 */
 	PM_HASGAM_ZDQ       = 13, /* ex-zd                  press.h:960-964 */
 	PM_ZSTD_HASGAM_ZDQ  = 14, /* zstd over ex-zd        press.c:8554 */
-	PM_NMETHODS         = 15
+	PM_SLOW5_SVB_ZD     = 15, /* BLOW5 signal codec "svb-zd": slow5lib slow5_press.c:1054,1110 */
+	PM_NMETHODS         = 16
 };
 
 #endif

@@ -695,6 +695,8 @@ uint64_t po_bound(int method, uint32_t n)
 	case PM_SHUFF_VBSSE21_ZD: return vb_zd_bound(n);                           /* press.c:3411,4409 */
 	case PM_HASGAM_ZDQ:       return svb32_bound((uint32_t) vb_zd_bound(n));   /* press.c:8461 */
 	case PM_ZSTD_HASGAM_ZDQ:  return zstd_bound_(svb32_bound((uint32_t) vb_zd_bound(n)));
+	/* slow5_press.c:1037: __slow5_streamvbyte_max_compressedbytes(n) (streamvbyte.h:31, no padding) + the u32 count */
+	case PM_SLOW5_SVB_ZD:     return (uint64_t) (n + 3) / 4 + (uint64_t) n * 4 + 4;
 	}
 	return 0;
 }
@@ -1000,6 +1002,26 @@ int po_press(int method, const int16_t *in, uint32_t n, uint8_t *out, uint64_t *
 	case PM_SHUFF_VBE21_ZD: case PM_SHUFF_VBBE21_ZD: case PM_SHUFF_VBSBE21_ZD:
 	case PM_SHUFF_VBSSE21_ZD:
 		return vb_family_press(method, in, n, out, nout);
+	case PM_SLOW5_SVB_ZD: {
+		/* slow5_press.c:1054 ptr_compress_svb_zd: samples widened to int32, zig-zag delta in 32 bits
+		 * (streamvbyte_zigzag.c:15, prev = 0: a jump of more than 32767 takes 17 bits - unlike
+		 * trans.c:233, which wraps at 16), svb32 of that behind the u32 sample count (:1034) */
+		uint32_t *z32;
+		int32_t prev = 0;
+		uint32_t i;
+		if (4 + (uint64_t) (n + 3) / 4 + (uint64_t) n * 3 > *nout)
+			return -1;
+		z32 = malloc(((size_t) n + 1) * sizeof *z32);
+		for (i = 0; i < n; i++) {
+			const int32_t d = (int32_t) in[i] - prev;
+			z32[i] = ((uint32_t) d << 1) ^ (uint32_t) (d >> 31);
+			prev = in[i];
+		}
+		put_u32(out, n);
+		*nout = 4 + po_svb32_encode(z32, n, out + 4);
+		free(z32);
+		return 0;
+	}
 	}
 	return -2;
 }
@@ -1034,6 +1056,39 @@ int po_depress(int method, const uint8_t *in, uint64_t nbytes, uint32_t n,
 	case PM_SHUFF_VBE21_ZD: case PM_SHUFF_VBBE21_ZD: case PM_SHUFF_VBSBE21_ZD:
 	case PM_SHUFF_VBSSE21_ZD:
 		return vb_family_depress(method, in, nbytes, n, out, nout);
+	case PM_SLOW5_SVB_ZD: {
+		/* slow5_press.c:1110 ptr_depress_svb_zd -> :1085 ptr_depress_svb: the count comes from
+		 * the stream and the decoder must consume exactly the bytes it was given (:1098);
+		 * streamvbyte_zigzag.c:34: 32-bit running sum, stored as int16.  n = room in `out`. */
+		uint32_t cnt, i;
+		uint32_t *z32;
+		uint64_t need, used;
+		int32_t prev = 0;
+		if (nbytes < 4)
+			return -1;
+		cnt = get_u32(in);
+		if (cnt > n)
+			return -1;
+		/* does the stream hold the bytes its keys announce?  (the reference would read past it) */
+		need = (uint64_t) (cnt + 3) / 4;
+		if (4 + need > nbytes)
+			return -1;
+		for (i = 0; i < cnt; i++)
+			need += 1 + ((in[4 + (i >> 2)] >> (2 * (i & 3))) & 3);
+		if (4 + need != nbytes)
+			return -1;
+		z32 = malloc(((size_t) cnt + 1) * sizeof *z32);
+		used = po_svb32_decode(in + 4, cnt, z32);
+		(void) used;
+		for (i = 0; i < cnt; i++) {
+			const int32_t val = (int32_t) (z32[i] >> 1) ^ -(int32_t) (z32[i] & 1);
+			out[i] = (int16_t) (val + prev);
+			prev += val;
+		}
+		free(z32);
+		*nout = cnt;
+		return 0;
+	}
 	}
 	return -2;
 }
