@@ -15,6 +15,9 @@
 //         u32 read_group | f64 digitisation, offset, range, sampling_rate | u64 len_raw_signal |
 //         signal | auxiliary fields.   len_raw_signal counts BYTES when the signal is
 //         compressed (slow5.c:3960) and samples when it is not.
+// The writer is the other direction (slow5_write / slow5_rec_to_mem, slow5.c:3903-4010): it copies
+// the source file's header, takes records whose signal field the caller has replaced (e.g. by the
+// device's svb-zd encoding) and frames them - so a compressor can emit BLOW5 directly.
 // Host code only: no HIP call in this file.
 
 #include <dlfcn.h>
@@ -42,6 +45,8 @@ int b5_fail(int code, const char *msg)
 struct Inflaters {
 	void *hz = nullptr, *hs = nullptr;
 	int (*z_uncompress)(unsigned char *, unsigned long *, const unsigned char *, unsigned long) = nullptr;
+	int (*z_compress2)(unsigned char *, unsigned long *, const unsigned char *, unsigned long, int) = nullptr;
+	unsigned long (*z_bound)(unsigned long) = nullptr;
 	size_t (*zs_decompress)(void *, size_t, const void *, size_t) = nullptr;
 	unsigned long long (*zs_content_size)(const void *, size_t) = nullptr;
 	unsigned (*zs_is_error)(size_t) = nullptr;
@@ -55,8 +60,11 @@ struct Inflaters {
 			if ((hz = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
 				break;
 		}
-		if (hz)
+		if (hz) {
 			z_uncompress = (decltype(z_uncompress)) dlsym(hz, "uncompress");
+			z_compress2 = (decltype(z_compress2)) dlsym(hz, "compress2");
+			z_bound = (decltype(z_bound)) dlsym(hz, "compressBound");
+		}
 		for (const char *n : { "libzstd.so.1", "libzstd.so", "/opt/conda/lib/libzstd.so.1" }) {
 			if ((hs = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
 				break;
@@ -77,6 +85,7 @@ struct press_hip_blow5 {
 	uint8_t version[3] = { 0, 0, 0 };
 	uint32_t num_read_groups = 0;
 	std::string header;
+	uint8_t fixed[68];              // the 64-byte binary header + the text header's size
 	std::vector<uint8_t> comp, rec; // one record: as stored, inflated
 	bool have_pending = false;      // `rec` holds a record that did not fit the last batch
 	bool at_eof = false;
@@ -148,6 +157,7 @@ struct RecView {
 	uint32_t id_len;
 	const uint8_t *sig;
 	uint64_t sig_bytes;
+	uint64_t sig_pos; // offset of the signal field in the inflated record (its u64 length sits 8 bytes before)
 	uint32_t nsamples;
 };
 
@@ -172,6 +182,7 @@ int parse_record(const press_hip_blow5 *f, RecView *v)
 	if (bytes > r.size() - p)
 		return b5_fail(PRESS_HIP_EARG, "BLOW5: signal field runs past the record");
 	v->sig = r.data() + p;
+	v->sig_pos = p;
 	v->sig_bytes = bytes;
 	if (f->signal_method) {
 		if (bytes < 4)
@@ -205,6 +216,7 @@ int press_hip_blow5_open(const char *path, press_hip_blow5 **out)
 	}
 	press_hip_blow5 *f = new press_hip_blow5;
 	f->fp = fp;
+	memcpy(f->fixed, h, sizeof h);
 	memcpy(f->version, h + 6, 3);
 	f->record_method = h[9];
 	memcpy(&f->num_read_groups, h + 10, 4);
@@ -290,6 +302,141 @@ int press_hip_blow5_next(press_hip_blow5 *f, uint32_t max_reads, uint8_t *arena,
 	}
 	*got = k;
 	return 0;
+}
+
+
+// Whole (inflated) records for a transcoder: as press_hip_blow5_next, but the arena receives the
+// records themselves; sig_pos / sig_len locate the signal field inside record k (the u64 in front
+// of it is its length field: bytes when the file compresses signals, samples when it does not).
+int press_hip_blow5_next_records(press_hip_blow5 *f, uint32_t max_reads, uint8_t *arena, uint64_t arena_cap,
+				 uint64_t *rec_off, uint64_t *rec_len, uint64_t *sig_pos, uint64_t *sig_len,
+				 uint32_t *n_samples, uint32_t *got)
+{
+	if (!f || !arena || !rec_off || !rec_len || !sig_pos || !sig_len || !n_samples || !got)
+		return b5_fail(PRESS_HIP_EARG, "BLOW5: NULL argument");
+	uint32_t k = 0;
+	uint64_t used = 0;
+	while (k < max_reads) {
+		if (!f->have_pending) {
+			if (f->at_eof)
+				break;
+			const int rc = next_record(f);
+			if (rc == 1)
+				break;
+			if (rc)
+				return rc;
+		}
+		f->have_pending = true;
+		RecView v;
+		int rc = parse_record(f, &v);
+		if (rc)
+			return rc;
+		const uint64_t at = (used + 15) & ~15ull;
+		if (at + f->rec.size() > arena_cap) {
+			if (k == 0)
+				return b5_fail(PRESS_HIP_EARG, "BLOW5: the arena cannot hold even one record");
+			break;
+		}
+		memcpy(arena + at, f->rec.data(), f->rec.size());
+		rec_off[k] = at;
+		rec_len[k] = f->rec.size();
+		sig_pos[k] = v.sig_pos;
+		sig_len[k] = v.sig_bytes;
+		n_samples[k] = v.nsamples;
+		used = at + f->rec.size();
+		f->have_pending = false;
+		k++;
+	}
+	*got = k;
+	return 0;
+}
+
+struct press_hip_blow5_writer {
+	FILE *fp = nullptr;
+	int record_method = 0, signal_method = 0;
+	std::vector<uint8_t> rec, comp;
+};
+
+int press_hip_blow5_create(const char *path, const press_hip_blow5 *like, int record_method, int signal_method,
+			   press_hip_blow5_writer **out)
+{
+	if (!path || !like || !out)
+		return b5_fail(PRESS_HIP_EARG, "BLOW5: NULL argument");
+	if (record_method < 0 || record_method > 1 || signal_method < 0 || signal_method > 1)
+		return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: record method none / zlib, signal method none / svb-zd");
+	if (record_method == 1) {
+		inf.open();
+		if (!inf.z_compress2 || !inf.z_bound)
+			return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: zlib record compression but libz is not available");
+	}
+	FILE *fp = fopen(path, "wb");
+	if (!fp)
+		return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: cannot create the file");
+	uint8_t h[68];
+	memcpy(h, like->fixed, sizeof h);
+	// the signal method byte exists from 0.2.0 on (slow5.c:4640): lift older headers
+	if (h[6] == 0 && h[7] < 2) {
+		h[7] = 2;
+		h[8] = 0;
+	}
+	h[9] = (uint8_t) record_method;
+	h[14] = (uint8_t) signal_method;
+	if (fwrite(h, 1, sizeof h, fp) != sizeof h ||
+	    (like->header.size() && fwrite(like->header.data(), 1, like->header.size(), fp) != like->header.size())) {
+		fclose(fp);
+		return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: write failed");
+	}
+	press_hip_blow5_writer *w = new press_hip_blow5_writer;
+	w->fp = fp;
+	w->record_method = record_method;
+	w->signal_method = signal_method;
+	*out = w;
+	return 0;
+}
+
+// One record: `pre` = everything in front of the signal's length field (read id ... sampling
+// rate), `sig` = the signal field in the writer's signal method, `post` = the auxiliary fields.
+int press_hip_blow5_write(press_hip_blow5_writer *w, const uint8_t *pre, uint64_t pre_len, const uint8_t *sig,
+			  uint64_t sig_len, const uint8_t *post, uint64_t post_len)
+{
+	if (!w || !pre || (!sig && sig_len) || (!post && post_len))
+		return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: NULL argument");
+	const uint64_t lenfield = w->signal_method ? sig_len : sig_len / 2; // slow5.c:3960
+	w->rec.resize(pre_len + 8 + sig_len + post_len);
+	memcpy(w->rec.data(), pre, pre_len);
+	memcpy(w->rec.data() + pre_len, &lenfield, 8);
+	if (sig_len)
+		memcpy(w->rec.data() + pre_len + 8, sig, sig_len);
+	if (post_len)
+		memcpy(w->rec.data() + pre_len + 8 + sig_len, post, post_len);
+	const uint8_t *body = w->rec.data();
+	uint64_t n = w->rec.size();
+	if (w->record_method == 1) {
+		unsigned long cap = inf.z_bound((unsigned long) n);
+		w->comp.resize(cap);
+		if (inf.z_compress2(w->comp.data(), &cap, body, (unsigned long) n, -1 /* Z_DEFAULT_COMPRESSION */))
+			return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: zlib failed");
+		body = w->comp.data();
+		n = cap;
+	}
+	if (fwrite(&n, 8, 1, w->fp) != 1 || fwrite(body, 1, n, w->fp) != n)
+		return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: write failed");
+	return 0;
+}
+
+int press_hip_blow5_finish(press_hip_blow5_writer *w)
+{
+	if (!w)
+		return 0;
+	int rc = 0;
+	if (w->fp) {
+		if (fwrite("5WOLB", 1, 5, w->fp) != 5)
+			rc = b5_fail(PRESS_HIP_EARG, "BLOW5 writer: write failed");
+		if (fclose(w->fp))
+			rc = b5_fail(PRESS_HIP_EARG, "BLOW5 writer: close failed");
+	}
+	delete w;
+	return rc;
 }
 
 } // extern "C"

@@ -71,7 +71,8 @@ HEADER_SYMBOLS = sorted(set(
      "press_hip_kernel_timing", "press_hip_kernel_times",
      "press_hip_slow5_ptr_compress_svb_zd", "press_hip_slow5_ptr_depress_svb_zd",
      "press_hip_blow5_open", "press_hip_blow5_close", "press_hip_blow5_methods", "press_hip_blow5_next",
-     "press_hip_blow5_last_error",
+     "press_hip_blow5_last_error", "press_hip_blow5_next_records", "press_hip_blow5_create",
+     "press_hip_blow5_write", "press_hip_blow5_finish",
      "press_hip_shutdown"]))
 
 
@@ -424,3 +425,62 @@ class Blow5Reader:
         if self._h:
             load_library().press_hip_blow5_close(self._h)
             self._h = ctypes.c_void_p()
+
+
+def blow5_transcode(src, dst, record_method=1, signal_method=1, codec=None):
+    """BLOW5 -> BLOW5 with the signal fields re-coded: codec(list of int16 arrays) -> list of svb-zd
+    streams (default: the device, press_batch_host("slow5_svb_zd")); signal_method 0 writes the raw
+    samples.  Signals of the source are decoded on the device when it stores them as svb-zd.
+    Returns the number of reads written."""
+    lib = load_library()
+    lib.press_hip_blow5_last_error.restype = ctypes.c_char_p
+    rd = Blow5Reader(src)
+    lib.press_hip_blow5_next_records.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64] + \
+        [ctypes.c_void_p] * 5 + [ctypes.POINTER(ctypes.c_uint32)]
+    lib.press_hip_blow5_create.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                           ctypes.POINTER(ctypes.c_void_p)]
+    lib.press_hip_blow5_write.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                          ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    lib.press_hip_blow5_finish.argtypes = [ctypes.c_void_p]
+    w = ctypes.c_void_p()
+    if lib.press_hip_blow5_create(dst.encode(), rd._h, record_method, signal_method, ctypes.byref(w)):
+        rd.close()
+        raise PressError(lib.press_hip_blow5_last_error().decode())
+    total = 0
+    try:
+        maxr, cap = 1024, 1 << 28
+        arena = np.empty(cap, dtype=np.uint8)
+        ro, rl, sp, sl = (np.zeros(maxr, dtype=np.uint64) for _ in range(4))
+        ns = np.zeros(maxr, dtype=np.uint32)
+        got = ctypes.c_uint32()
+        while True:
+            if lib.press_hip_blow5_next_records(rd._h, maxr, arena.ctypes.data, cap, ro.ctypes.data, rl.ctypes.data,
+                                                sp.ctypes.data, sl.ctypes.data, ns.ctypes.data, ctypes.byref(got)):
+                raise PressError(lib.press_hip_blow5_last_error().decode())
+            if got.value == 0:
+                break
+            recs = [arena[int(ro[k]):int(ro[k]) + int(rl[k])] for k in range(got.value)]
+            fields = [r[int(sp[k]):int(sp[k]) + int(sl[k])].tobytes() for k, r in enumerate(recs)]
+            if rd.signal_method == 1:
+                sigs = depress_batch_host("slow5_svb_zd", fields, [int(x) for x in ns[:got.value]])
+                if any(s is None for s in sigs):
+                    raise PressError("a signal of %s does not decode" % src)
+            else:
+                sigs = [np.frombuffer(f, dtype=np.int16) for f in fields]
+            if signal_method == 1:
+                out = (codec or (lambda reads: press_batch_host("slow5_svb_zd", reads)))(sigs)
+            else:
+                out = [np.ascontiguousarray(s, dtype=np.int16).tobytes() for s in sigs]
+            for k, r in enumerate(recs):
+                pre = r[:int(sp[k]) - 8]
+                post = r[int(sp[k]) + int(sl[k]):]
+                ob = np.frombuffer(out[k], dtype=np.uint8)
+                if lib.press_hip_blow5_write(w, pre.ctypes.data, pre.size, ob.ctypes.data, ob.size,
+                                             post.ctypes.data if post.size else None, post.size):
+                    raise PressError(lib.press_hip_blow5_last_error().decode())
+            total += got.value
+    finally:
+        rd.close()
+        if lib.press_hip_blow5_finish(w):
+            raise PressError(lib.press_hip_blow5_last_error().decode())
+    return total

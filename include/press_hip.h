@@ -267,6 +267,20 @@ int press_hip_blow5_methods(const press_hip_blow5 *f, int *record_method, int *s
 int press_hip_blow5_next(press_hip_blow5 *f, uint32_t max_reads, uint8_t *arena, uint64_t arena_cap,
 			 uint64_t *sig_off, uint64_t *sig_len, uint32_t *n_samples, char *read_ids, uint32_t *got);
 const char *press_hip_blow5_last_error(void);
+/* Whole inflated records (for a transcoder): sig_pos / sig_len locate the signal field in
+ * record k, the u64 length field sits 8 bytes in front of it. */
+int press_hip_blow5_next_records(press_hip_blow5 *f, uint32_t max_reads, uint8_t *arena, uint64_t arena_cap,
+				 uint64_t *rec_off, uint64_t *rec_len, uint64_t *sig_pos, uint64_t *sig_len,
+				 uint32_t *n_samples, uint32_t *got);
+/* Writer (slow5_write / slow5_rec_to_mem, slow5.c:3903-4010): header copied from `like`; records
+ * framed and - record_method 1 - deflated; signal_method says what `sig` holds (0: int16 samples,
+ * 1: svb-zd, e.g. the output of press_hip_press_batch(PRESS_HIP_SLOW5_SVB_ZD, ...)). */
+typedef struct press_hip_blow5_writer press_hip_blow5_writer;
+int press_hip_blow5_create(const char *path, const press_hip_blow5 *like, int record_method, int signal_method,
+			   press_hip_blow5_writer **out);
+int press_hip_blow5_write(press_hip_blow5_writer *w, const uint8_t *pre, uint64_t pre_len, const uint8_t *sig,
+			  uint64_t sig_len, const uint8_t *post, uint64_t post_len);
+int press_hip_blow5_finish(press_hip_blow5_writer *w); /* end marker, close, free */
 
 #ifdef __cplusplus
 }

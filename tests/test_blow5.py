@@ -154,3 +154,45 @@ def test_gpu_wide_jumps_and_ragged(oracle):
         ro, _ = oracle.depress("slow5_svb_zd", bad, n + 8)
         rg, bg = press.depress("slow5_svb_zd", bad, n + 8)
         assert ro != 0 and rg != 0
+
+
+def _ref_dump(path, tmp_path):
+    """the reference's slow5lib reads `path` (oracle/_ref/ref_dump_blow5) -> {read_id: samples}"""
+    import subprocess
+    tool = os.path.join(_libs.ORACLE_DIR, "_ref", "ref_dump_blow5")
+    if not os.path.exists(tool):
+        pytest.skip("oracle/_ref/ref_dump_blow5 is not built here")
+    out = str(tmp_path / "dump.bin")
+    subprocess.run([tool, path, out], check=True, stderr=subprocess.DEVNULL)
+    d = open(out, "rb").read()
+    nreads, = struct.unpack("<I", d[:4])
+    p, res = 4, {}
+    for _ in range(nreads):
+        idl, = struct.unpack("<I", d[p:p + 4])
+        rid = d[p + 4:p + 4 + idl].decode()
+        n, = struct.unpack("<Q", d[p + 4 + idl:p + 12 + idl])
+        p += 12 + idl
+        res[rid] = np.frombuffer(d[p:p + 2 * n], dtype=np.int16)
+        p += 2 * n
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rec,sig", [(0, 1), (1, 1), (1, 0)])
+def test_gpu_transcode_is_read_by_the_reference(tmp_path, rec, sig):
+    """BLOW5 -> (reader, device svb-zd decode, device svb-zd encode, writer) -> BLOW5: the
+    reference's own slow5lib opens the result and finds the same reads; with record compression
+    off the svb-zd fields are the bytes of the source file"""
+    press.load_library()
+    dst = str(tmp_path / "out.blow5")
+    assert press.blow5_transcode(BLOW5, dst, record_method=rec, signal_method=sig) == 3
+    gold = golden_reads()
+    got = _ref_dump(dst, tmp_path)
+    assert set(got) == set(gold)
+    for rid in gold:
+        assert np.array_equal(got[rid], gold[rid]), rid
+    rd = press.Blow5Reader(dst)
+    assert (rd.record_method, rd.signal_method) == (rec, sig)
+    if sig == 1:
+        assert [(i, s) for i, _, s in rd.next_batch()] == parse_blow5_py(BLOW5)
+    rd.close()
