@@ -589,6 +589,7 @@ extern "C" int press_hip_press_batch(int method, const int16_t *sig, const uint6
 	a.max_chunks = max_chunks_of(total_samples, nreads);
 	if (is_shuff(method))
 		a.gran2 = (uint64_t *) g.gran2.p;
+	a.first_chunk = (uint32_t *) g.first_chunk.p;
 
 	if (device_resident) {
 		if ((uintptr_t) sig & 15)

@@ -1090,6 +1090,62 @@ __device__ __forceinline__ uint32_t exc_mask(const uint4 &z, uint32_t i0)
 	return m;
 }
 
+// raw samples of a lane's 8 samples of a sub-tile (zeros at or beyond n)
+__device__ __forceinline__ uint4 sub_load(const int16_t *in, uint32_t n, uint32_t i0)
+{
+	uint4 r = make_uint4(0, 0, 0, 0);
+	if (i0 < n)
+		r = *reinterpret_cast<const uint4 *>(in + i0);
+	return r;
+}
+
+// their zig-zag deltas (trans.c:75,215), after the ex-zd shift q (ex_zd.c:383).  carry = the
+// (raw) sample in front of the sub-tile in bits 16..31; returns the sub-tile's last sample the
+// same way for the next one.  ored |= the raw samples below n (qts, ex_zd.c:358).
+__device__ __forceinline__ uint4 sub_zd(uint4 raw, uint32_t n, uint32_t i0, uint32_t &carry, int q = 0,
+					uint32_t *ored = nullptr)
+{
+	uint32_t r[4] = { raw.x, raw.y, raw.z, raw.w };
+	const uint32_t nv = i0 + 8 <= n ? 8u : (i0 < n ? n - i0 : 0u);
+	if (nv < 8) {
+#pragma unroll
+		for (int h = 0; h < 4; h++) {
+			if (nv <= (uint32_t) (2 * h))
+				r[h] = 0;
+			else if (nv == (uint32_t) (2 * h + 1))
+				r[h] &= 0xFFFFu;
+		}
+	}
+	if (ored)
+		*ored |= r[0] | r[1] | r[2] | r[3];
+	const uint32_t raw_w = r[3];
+	uint32_t c = carry;
+	if (q) {
+		const s16x2 qq = { (short) q, (short) q };
+#pragma unroll
+		for (int h = 0; h < 4; h++)
+			r[h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, r[h]) >> qq);
+		c = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, c) >> qq);
+	}
+	const uint32_t pw = prev_lane(r[3], c);
+	uint32_t zz[4];
+	zz[0] = zd_pair(r[0], pw);
+	zz[1] = zd_pair(r[1], r[0]);
+	zz[2] = zd_pair(r[2], r[1]);
+	zz[3] = zd_pair(r[3], r[2]);
+	carry = (uint32_t) __builtin_amdgcn_readlane((int) raw_w, 63);
+	if (nv < 8) { // deltas of samples beyond n are garbage
+#pragma unroll
+		for (int h = 0; h < 4; h++) {
+			if (nv <= (uint32_t) (2 * h))
+				zz[h] = 0;
+			else if (nv == (uint32_t) (2 * h + 1))
+				zz[h] &= 0xFFFFu;
+		}
+	}
+	return make_uint4(zz[0], zz[1], zz[2], zz[3]);
+}
+
 // ex-zd: does any read of the batch need the second scan (all samples divisible by 2^q, q > 0)?
 __global__ __launch_bounds__(256) void k_ex_redo_flag(BatchArgs a)
 {
@@ -1098,118 +1154,158 @@ __global__ __launch_bounds__(256) void k_ex_redo_flag(BatchArgs a)
 		atomicOr(&a.ctl->pad0[0], 1u);
 }
 
+// Pass A.  Nothing chains the chunks here: every workgroup streams its chunk once (four sub-tiles
+// in flight per wave) and leaves, per wave quarter, the number of exceptions and the sub-tiles that
+// hold one in the chunk descriptor; k_ex_prefix turns the counts into ranks and k_ex_list
+// writes the (few) exceptions at their final rank from the flagged sub-tiles alone.
 template <bool REDO>
 __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 {
-	__shared__ uint32_t s_ticket;
-	__shared__ uint32_t s_wtot[4];
-	__shared__ uint64_t s_excl;
-
 	if (REDO && uni(a.ctl->pad0[0]) == 0)
 		return; // no read of this batch has q > 0 (the common case)
-	const uint32_t nchunks = uni(a.ctl->nchunks);
+	const uint32_t t = blockIdx.x;
+	if (t >= uni(a.ctl->nchunks))
+		return;
 	const int lane = threadIdx.x & 63;
 	const int w = (int) uni(threadIdx.x >> 6);
-	for (;;) {
-		if (threadIdx.x == 0)
-			s_ticket = atomicAdd(&a.ctl->ticket, 1u);
-		__syncthreads();
-		const uint32_t t = uni(s_ticket);
-		if (t >= nchunks)
-			break;
-		ChunkDesc *dp = a.chunks + t;
-		const ChunkU d = load_chunk(dp);
-		const uint32_t n = d.n;
-		const uint32_t first = d.j * CHUNK;
-		const bool last = first + CHUNK >= n;
-		ReadMeta *m = a.meta + d.read;
-		int q = 0;
-		if (REDO) {
-			const uint32_t ored = uni(m->ored);
-			// ex_zd.c:358-381: largest q <= 5 with every sample divisible by 2^q
-			while (q < 5 && !((ored >> q) & 1u))
-				q++;
-			if (q == 0) { // nothing to redo for this read (same decision in all its chunks)
-				__syncthreads();
-				continue;
-			}
-		}
-		const int16_t *in = a.sig + d.sig_off;
-		uint32_t *lpos = a.ex_pos + d.sig_off;
-		uint32_t *lval = a.ex_val + d.sig_off;
-		const uint32_t ws = first + w * WAVE_SAMPLES;
+	ChunkDesc *dp = a.chunks + t;
+	const ChunkU d = load_chunk(dp);
+	const uint32_t n = d.n;
+	const uint32_t first = d.j * CHUNK;
+	ReadMeta *m = a.meta + d.read;
+	int q = 0;
+	if (REDO) {
+		const uint32_t ored = uni(m->ored);
+		// ex_zd.c:358-381: largest q <= 5 with every sample divisible by 2^q
+		while (q < 5 && !((ored >> q) & 1u))
+			q++;
+		if (q == 0)
+			return; // nothing to redo for this read
+	}
+	const int16_t *in = a.sig + d.sig_off;
+	const uint32_t ws = first + w * WAVE_SAMPLES;
+	if (ws >= n)
+		return; // the descriptor's counts are zero already
 
-		uint4 z[CK];
-		uint32_t ored;
-		quarter_zd(in, n, ws, lane, q, z, ored);
-		uint32_t kmask = 0, etot = 0;
+	uint32_t kmask = 0, etot = 0, ored32 = 0, zd0 = 0;
+	uint32_t carry = 0; // the sample in front of the sub-tile
+	if (ws > 0)
+		carry = (uint32_t) (uint16_t) in[ws - 1] << 16;
+	uint4 raw[4];
 #pragma unroll
-		for (int k = 0; k < CK; k++) {
-			const uint32_t i0 = ws + k * SUB + lane * 8;
-			uint32_t hi = (z[k].x | z[k].y | z[k].z | z[k].w) & 0xFF00FF00u;
+	for (int k = 0; k < 4; k++)
+		raw[k] = sub_load(in, n, ws + k * SUB + lane * 8);
+#pragma unroll 1
+	for (int kk = 0; kk < CK; kk += 4) {
+		uint4 nxt[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+			nxt[k] = kk + 4 + k < CK ? sub_load(in, n, ws + (kk + 4 + k) * SUB + lane * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const uint32_t i0 = ws + (kk + k) * SUB + lane * 8;
+			const uint4 z = sub_zd(raw[k], n, i0, carry, q, &ored32);
+			if (kk + k == 0)
+				zd0 = z.x & 0xFFFFu; // lane 0 of the read's first quarter: zd[0]
+			uint32_t hi = (z.x | z.y | z.z | z.w) & 0xFF00FF00u;
 			if (i0 == 0)
-				hi = ((z[k].x & 0xFF000000u) | ((z[k].y | z[k].z | z[k].w) & 0xFF00FF00u));
+				hi = ((z.x & 0xFF000000u) | ((z.y | z.z | z.w) & 0xFF00FF00u));
 			if (__ballot(hi != 0)) {
-				kmask |= 1u << k;
-				const uint32_t inc = wave_incl_scan_dpp(__popc(exc_mask(z[k], i0)));
+				kmask |= 1u << (kk + k);
+				const uint32_t inc = wave_incl_scan_dpp(__popc(exc_mask(z, i0)));
 				etot += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
 			}
 		}
-		if (!REDO) { // OR of the raw samples (qts), one atomic per wave
-			uint32_t o = ored;
 #pragma unroll
-			for (int dd = 32; dd >= 1; dd >>= 1)
-				o |= (uint32_t) __shfl_xor((int) o, dd, 64);
-			if (lane == 0 && ws < n)
-				atomicOr(&m->ored, o);
-		}
+		for (int k = 0; k < 4; k++)
+			raw[k] = nxt[k];
+	}
+	if (!REDO) { // OR of the raw samples (qts), one atomic per wave
+		uint32_t o = (ored32 | (ored32 >> 16)) & 0xFFFFu;
+#pragma unroll
+		for (int dd = 32; dd >= 1; dd >>= 1)
+			o |= (uint32_t) __shfl_xor((int) o, dd, 64);
 		if (lane == 0)
-			s_wtot[w] = etot;
-		__syncthreads();
-		const uint32_t t0 = uni(s_wtot[0]), t1 = uni(s_wtot[1]), t2 = uni(s_wtot[2]), t3 = uni(s_wtot[3]);
-		if (w == 0) {
-			const uint64_t e = lookback(a.gran, t, d.j, (uint64_t) t0 + t1 + t2 + t3, last);
-			if (lane == 0) {
-				s_excl = e;
-				dp->ebefore = e;
-				dp->ecnt[0] = t0;
-				dp->ecnt[1] = t1;
-				dp->ecnt[2] = t2;
-				dp->ecnt[3] = t3;
-				if (last) {
-					m->nex = (uint32_t) e + t0 + t1 + t2 + t3;
-					m->q = (uint32_t) q;
+			atomicOr(&m->ored, o);
+	}
+	if (lane == 0) {
+		dp->ecnt[w] = etot;
+		dp->kmask[w] = (uint16_t) kmask;
+		if (ws == 0)
+			m->zd0 = zd0;
+	}
+}
+
+// exceptions in front of every chunk (one thread per read); the read's total and its ex-zd shift
+__global__ __launch_bounds__(256) void k_ex_prefix(BatchArgs a, int exzd)
+{
+	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r >= a.nreads)
+		return;
+	const uint32_t n = a.nsamp[r];
+	if (n == 0)
+		return;
+	ReadMeta *m = a.meta + r;
+	ChunkDesc *dp = a.chunks + a.first_chunk[r];
+	const uint32_t nch = (n + CHUNK - 1) / CHUNK;
+	uint64_t e = 0;
+	for (uint32_t j = 0; j < nch; j++) {
+		dp[j].ebefore = e;
+		e += (uint64_t) dp[j].ecnt[0] + dp[j].ecnt[1] + dp[j].ecnt[2] + dp[j].ecnt[3];
+	}
+	m->nex = (uint32_t) e;
+	uint32_t q = 0;
+	if (exzd) { // ex_zd.c:358-381
+		const uint32_t ored = m->ored;
+		while (q < 5 && !((ored >> q) & 1u))
+			q++;
+	}
+	m->q = q;
+}
+
+// the exception list (position, value) at its final rank: only the flagged sub-tiles are read again
+__global__ __launch_bounds__(CWG) void k_ex_list(BatchArgs a)
+{
+	const uint32_t t = blockIdx.x;
+	if (t >= uni(a.ctl->nchunks))
+		return;
+	const int lane = threadIdx.x & 63;
+	const int w = (int) uni(threadIdx.x >> 6);
+	const ChunkDesc *dp = a.chunks + t;
+	const uint32_t kmask = uni(dp->kmask[w]);
+	if (!kmask)
+		return;
+	const ChunkU d = load_chunk(dp);
+	const uint32_t n = d.n;
+	const int q = (int) uni(a.meta[d.read].q);
+	const int16_t *in = a.sig + d.sig_off;
+	uint32_t *lpos = a.ex_pos + d.sig_off;
+	uint32_t *lval = a.ex_val + d.sig_off;
+	const uint32_t ws = d.j * CHUNK + w * WAVE_SAMPLES;
+	const uint32_t c0 = uni(dp->ecnt[0]), c1 = uni(dp->ecnt[1]), c2 = uni(dp->ecnt[2]);
+	uint32_t rank = (uint32_t) uni64(dp->ebefore) + (w > 0 ? c0 : 0u) + (w > 1 ? c1 : 0u) + (w > 2 ? c2 : 0u);
+	for (uint32_t mm = kmask; mm; mm &= mm - 1) {
+		const uint32_t k = (uint32_t) __builtin_ctz(mm);
+		const uint32_t sub0 = ws + k * SUB;
+		const uint32_t i0 = sub0 + lane * 8;
+		uint32_t carry = sub0 ? (uint32_t) (uint16_t) in[sub0 - 1] << 16 : 0u;
+		const uint4 z = sub_zd(sub_load(in, n, i0), n, i0, carry, q);
+		const uint32_t em = exc_mask(z, i0);
+		const uint32_t c = __popc(em);
+		const uint32_t inc = wave_incl_scan_dpp(c);
+		uint32_t p = rank + inc - c;
+		const uint32_t zz[4] = { z.x, z.y, z.z, z.w };
+		if (em) {
+#pragma unroll
+			for (int h = 0; h < 8; h++) {
+				if ((em >> h) & 1u) {
+					lpos[p] = i0 + h - 1;
+					lval[p] = (zz[h >> 1] >> (16 * (h & 1))) & 0xFFFFu;
+					p++;
 				}
 			}
 		}
-		__syncthreads();
-		uint32_t rank = (uint32_t) uni64(s_excl) + (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
-		if (first == 0 && threadIdx.x == 0)
-			m->zd0 = z[0].x & 0xFFFFu;
-		// ---- exception list at its final rank
-#pragma unroll
-		for (int k = 0; k < CK; k++) {
-			if (!((kmask >> k) & 1u))
-				continue;
-			const uint32_t i0 = ws + k * SUB + lane * 8;
-			const uint32_t em = exc_mask(z[k], i0);
-			const uint32_t c = __popc(em);
-			const uint32_t inc = wave_incl_scan_dpp(c);
-			uint32_t p = rank + inc - c;
-			const uint32_t zz[4] = { z[k].x, z[k].y, z[k].z, z[k].w };
-			if (em) {
-#pragma unroll
-				for (int h = 0; h < 8; h++) {
-					if ((em >> h) & 1u) {
-						lpos[p] = i0 + h - 1;
-						lval[p] = (zz[h >> 1] >> (16 * (h & 1))) & 0xFFFFu;
-						p++;
-					}
-				}
-			}
-			rank += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
-		}
-		__syncthreads(); // every wave has read s_ticket / s_excl before they are overwritten
+		rank += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
 	}
 }
 
@@ -1330,49 +1426,6 @@ __device__ __forceinline__ uint32_t low_mask(const uint4 &z, uint32_t i0, uint32
 	if ((z.x | z.y | z.z | z.w) & 0xFF00FF00u)
 		lowm &= ~exc_mask(z, i0);
 	return lowm;
-}
-
-// raw samples of a lane's 8 samples of a sub-tile (zeros at or beyond n)
-__device__ __forceinline__ uint4 sub_load(const int16_t *in, uint32_t n, uint32_t i0)
-{
-	uint4 r = make_uint4(0, 0, 0, 0);
-	if (i0 < n)
-		r = *reinterpret_cast<const uint4 *>(in + i0);
-	return r;
-}
-
-// their zig-zag deltas (trans.c:75,215; q = 0).  carry = the sample in front of the sub-tile
-// in bits 16..31; returns the sub-tile's last sample the same way for the next one.
-__device__ __forceinline__ uint4 sub_zd(uint4 raw, uint32_t n, uint32_t i0, uint32_t &carry)
-{
-	uint32_t r[4] = { raw.x, raw.y, raw.z, raw.w };
-	const uint32_t nv = i0 + 8 <= n ? 8u : (i0 < n ? n - i0 : 0u);
-	if (nv < 8) {
-#pragma unroll
-		for (int h = 0; h < 4; h++) {
-			if (nv <= (uint32_t) (2 * h))
-				r[h] = 0;
-			else if (nv == (uint32_t) (2 * h + 1))
-				r[h] &= 0xFFFFu;
-		}
-	}
-	const uint32_t pw = prev_lane(r[3], carry);
-	uint32_t zz[4];
-	zz[0] = zd_pair(r[0], pw);
-	zz[1] = zd_pair(r[1], r[0]);
-	zz[2] = zd_pair(r[2], r[1]);
-	zz[3] = zd_pair(r[3], r[2]);
-	carry = (uint32_t) __builtin_amdgcn_readlane((int) r[3], 63);
-	if (nv < 8) { // deltas of samples beyond n are garbage
-#pragma unroll
-		for (int h = 0; h < 4; h++) {
-			if (nv <= (uint32_t) (2 * h))
-				zz[h] = 0;
-			else if (nv == (uint32_t) (2 * h + 1))
-				zz[h] &= 0xFFFFu;
-		}
-	}
-	return make_uint4(zz[0], zz[1], zz[2], zz[3]);
 }
 
 __global__ __launch_bounds__(CWG) void k_huff_encode_chunked(BatchArgs a)
@@ -1683,6 +1736,9 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 
 	const int lane = threadIdx.x & 63;
 	const int w = (int) uni(threadIdx.x >> 6);
+#ifdef DEC_STAMPS
+	const uint64_t t_start = __builtin_amdgcn_s_memtime();
+#endif
 	if (threadIdx.x == 0)
 		s_ticket = atomicAdd(&a.ctl->ticket, 1u);
 	if (lane < CK)
@@ -1693,6 +1749,11 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 	const uint32_t t = uni(s_ticket);
 	if (t >= a.ctl->nchunks)
 		return;
+#ifdef DEC_STAMPS
+	if (threadIdx.x == 0 && t < 65536)
+		g_stamps[t * 8 + 0] = t_start;
+#endif
+	STAMP(1);
 	const ChunkU d = load_chunk(a.chunks + t);
 	const uint32_t n = d.n;
 	const uint32_t first = d.j * CHUNK;
@@ -1741,6 +1802,7 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 			kmask |= 1u << k;
 	kmask &= live;
 	const uint32_t plain = live & ~kmask;
+	STAMP(2);
 
 	// ---- phase 1: one-byte values of the plain sub-tiles (8 per lane, any alignment)
 	uint2 dat[CK];
@@ -1802,7 +1864,9 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 	wave_lds_sync();
 	if (lane == 0)
 		s_wsum[w] = wtot & 0xFFFFu;
+	STAMP(3);
 	__syncthreads();
+	STAMP(4);
 	const uint32_t u0 = uni(s_wsum[0]), u1 = uni(s_wsum[1]), u2 = uni(s_wsum[2]), u3 = uni(s_wsum[3]);
 	if (w == 0) {
 		const uint32_t sv = (uint32_t) lookback(a.gran, t, d.j, (uint64_t) ((u0 + u1 + u2 + u3) & 0xFFFFu), last);
@@ -1810,6 +1874,7 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 			s_sbase = sv;
 	}
 	__syncthreads();
+	STAMP(5);
 	const uint32_t sb = uni(s_sbase) + (w > 0 ? u0 : 0u) + (w > 1 ? u1 : 0u) + (w > 2 ? u2 : 0u);
 
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1869,6 +1934,7 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 					out[i0 + h] = (int16_t) (v[h >> 1] >> (16 * (h & 1)));
 		}
 	}
+	STAMP(6);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -1927,15 +1993,16 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL((k_chunk_prep<false, false>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
 			   a.nsamp, a.out_off, (const uint64_t *) nullptr, a.nreads, a.chunks, a.gran, a.ctl,
-			   a.max_chunks, a.out_len, (uint32_t *) nullptr, (uint32_t *) nullptr, a.meta, huff ? a.gran2 : nullptr);
-	hipLaunchKernelGGL((k_ex_scan_chunked<false>), dim3(grid), dim3(CWG), 0, s, a);
+			   a.max_chunks, a.out_len, (uint32_t *) nullptr, a.first_chunk, a.meta, huff ? a.gran2 : nullptr);
+	// surplus workgroups (max_chunks bounds the real count from above) exit at once
+	hipLaunchKernelGGL((k_ex_scan_chunked<false>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	if (fmt == EXF_EXZD) {
-		// second scan on the shifted samples for reads with q > 0 (fresh tickets and granules)
+		// second scan on the shifted samples for reads with q > 0
 		hipLaunchKernelGGL(k_ex_redo_flag, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a);
-		(void) hipMemsetAsync(&a.ctl->ticket, 0, sizeof(uint32_t), s);
-		(void) hipMemsetAsync(a.gran, 0, (size_t) a.max_chunks * sizeof(uint64_t), s);
-		hipLaunchKernelGGL((k_ex_scan_chunked<true>), dim3(grid), dim3(CWG), 0, s, a);
+		hipLaunchKernelGGL((k_ex_scan_chunked<true>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	}
+	hipLaunchKernelGGL(k_ex_prefix, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a, fmt == EXF_EXZD ? 1 : 0);
+	hipLaunchKernelGGL(k_ex_list, dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	launch_ex_section(a, fmt, huff, s);
 	ktime_begin(0, s);
 	if (huff)

@@ -100,6 +100,7 @@ struct BatchArgs {
 	ChunkCtl *ctl;            // zeroed per launch
 	uint32_t max_chunks;      // >= sum over reads of ceil(n / CHUNK)
 	uint64_t *gran2;          // [max_chunks] look-back granules of the Huffman bit-count chain
+	uint32_t *first_chunk;    // [nreads] id of the first chunk of read r (exception-split encode)
 };
 
 struct HufTile {             // one tile of a read's Huffman payload (press_huffman.hip), 32 bytes

@@ -1,9 +1,10 @@
-"""diagnostic: per-phase wave-0 timing of k_svb_decode_chunked (DEC_STAMPS build)"""
+"""diagnostic: per-phase wave-0 timing of k_svb_decode_chunked / k_low_decode_chunked (DEC_STAMPS build);
+extra arguments go to bench.py (e.g. --method vbe21_zd)"""
 import ctypes, os, sys, subprocess
 import numpy as np
 os.environ["PRESS_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libpress_stamps.so")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.argv = ["bench.py", "--steps", "1", "--warmup", "1", "--no-cpu"]
+sys.argv = ["bench.py", "--steps", "1", "--warmup", "1", "--no-cpu"] + sys.argv[1:]
 import runpy
 runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), run_name="__main__")
 from honours_amd import press
