@@ -6,10 +6,11 @@
 // the NA12878 table); one 512-thread workgroup per tile, handed out in ticket order by a
 // persistent grid that keeps the lookup tables in LDS (53 KB per workgroup: 3 per CU).
 // Thread i owns the codes that START in subsequence i:
-//   pass 0     thread i decodes subsequence i-1 from its first bit (thread 0: the last
-//              subsequence of the previous tile) and records where the first code of
-//              subsequence i starts, E[i-1];
-//   rounds     thread i takes E[i-1] as its start; whoever's start changed decodes again -
+//   pass 0     thread i runs up through subsequence i-1 from its first bit (thread 0: the last
+//              subsequence of the previous tile) to where the first code of subsequence i
+//              starts, then decodes its own subsequence from there;
+//   rounds     thread i takes the end E[i-1] of its left neighbour as its start; whoever's
+//              start differs from what it used decodes again -
 //              the changed threads are compacted so that a round with few changes costs a
 //              wave, not eight - until nothing changes (thread i is final after <= i rounds;
 //              in practice after 2-3).  These passes leave their symbols in a private
@@ -60,27 +61,21 @@ __device__ __forceinline__ uint32_t la(uint32_t j) { return j + (j >> 6); }
 // Decode the codes that start in [start, sub_end) of the image (bit positions relative to
 // the image); returns where the next code starts, or HEND.  nbits = end of the payload.
 // WRITE: symbols go to `slot`, their number to `cnt`.
-// LEAD: the codes that start below `mid` are only a run-up from a guessed position - not
-// written, not counted; `first` returns where the first code at or after `mid` starts (HEND if
-// the payload ends before).  A run-up that hits a bit pattern that is no code restarts at mid.
 // The lane keeps a 64-bit window {hi, lo} of the stream in registers and fetches the dword
 // after it while the table lookup is in flight, so a step costs one LDS round trip.
-template <bool WRITE, bool LEAD>
+template <bool WRITE>
 __device__ __forceinline__ uint32_t huff_run(const uint32_t *lbits, const uint32_t *lut, const uint16_t *lut2,
 					     const uint16_t *l2off, const uint8_t *l2bits, const HuffDev *hd,
-					     uint32_t start, uint32_t mid, uint32_t sub_end, uint32_t nbits, uint32_t &cnt,
-					     uint8_t *slot, uint32_t &first)
+					     uint32_t start, uint32_t sub_end, uint32_t nbits, uint32_t &cnt, uint8_t *slot)
 {
 	bool bad = start == HEND;
 	uint32_t p = bad ? 0u : start;
 	uint32_t lim = sub_end < nbits ? sub_end : nbits; // codes must START below this
 	if (bad)
 		lim = 0;
-	const uint32_t lim1 = mid < nbits ? mid : nbits;  // ... run-up codes below this
 	uint32_t c = 0;
 	uint32_t j = p >> 5;
 	uint32_t lo = lbits[la(j)], hi = lbits[la(j) + 1];
-	uint32_t f = p;
 	// wave-uniform and predicated: lanes need different numbers of steps, and per-lane
 	// branches cost more than the few masked operations
 	for (;;) {
@@ -88,7 +83,6 @@ __device__ __forceinline__ uint32_t huff_run(const uint32_t *lbits, const uint32
 		if (!__any(act))
 			break;
 		if (act) {
-			const bool own = !LEAD || p >= mid;
 			const uint32_t nxt = lbits[la(j + 2)];
 			// 32 stream bits from position p (codes are at most 24 bits long)
 			const uint32_t wnd = __builtin_amdgcn_alignbit(hi, lo, p & 31);
@@ -111,33 +105,24 @@ __device__ __forceinline__ uint32_t huff_run(const uint32_t *lbits, const uint32
 					ok = node >= 0 && hd->leaf[node] >= 0;
 					sym = ok ? (uint32_t) hd->leaf[node] : 0u;
 				}
-				if (!ok) {
+				if (!ok) { // no such code: the reference stops here
+					bad = true;
+					lim = 0;
 					len = 0;
-					if (LEAD && !own) { // a guess went wrong: any guess will do
-						p = mid;
-						j = p >> 5;
-						lo = lbits[la(j)];
-						hi = lbits[la(j) + 1];
-					} else { // no such code: the reference stops here
-						bad = true;
-						lim = 0;
-					}
 				}
 				e = sym | (len << 16) | (len << 21) | (ok ? (1u << 26) : 0u);
 			}
 			// e = sym1 | sym2 << 8 | len1 << 16 | (len1 + len2) << 21 | (codes: 1 or 2) << 26; the second
-			// code counts only if it starts inside this subsequence (run-up: below mid)
+			// code counts only if it starts inside this subsequence
 			const uint32_t len1 = (e >> 16) & 0x1Fu;
-			const bool both = p + len1 < (own ? lim : lim1);
-			if (WRITE && own) {
+			const bool both = p + len1 < lim;
+			if (WRITE) {
 				slot[c] = (uint8_t) e;
 				slot[c + 1] = (uint8_t) (e >> 8);
 				const uint32_t n2 = e >> 26;
 				c += both ? n2 : (n2 ? 1u : 0u);
 			}
 			p += both ? ((e >> 21) & 0x1Fu) : len1;
-			if (LEAD && !own)
-				f = p;
 			const uint32_t jn = p >> 5; // a step crosses at most one dword
 			if (jn != j) {
 				lo = hi;
@@ -152,7 +137,6 @@ __device__ __forceinline__ uint32_t huff_run(const uint32_t *lbits, const uint32
 		bad = true;
 	}
 	cnt = c;
-	first = (LEAD && f < mid) ? HEND : f; // the payload ended inside the run-up
 	return bad ? HEND : (p >= nbits && p < sub_end ? HEND : p);
 }
 
@@ -346,10 +330,9 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 				const uint32_t u = ent & 511u;
 				const bool end = (ent >> 14) & 1u;
 				const uint32_t rel = (ent >> 9) & 31u;
-				uint32_t c, f;
-				const uint32_t st = end ? HEND : (u + 1) * S + rel;
-				const uint32_t e = huff_run<true, false>(lbits, lut, lut2, l2off, l2bits, a.huff, st, st, (u + 2) * S, nbits,
-									 c, slots + u * HSLOT, f);
+				uint32_t c;
+				const uint32_t e = huff_run<true>(lbits, lut, lut2, l2off, l2bits, a.huff, end ? HEND : (u + 1) * S + rel,
+								  (u + 2) * S, nbits, c, slots + u * HSLOT);
 				if (mine) {
 					sS[u] = (uint8_t) (end ? ST_END : rel);
 					sE[u + 1] = (e == HEND ? PE_END : e) | (c << 24);
@@ -415,13 +398,22 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 		__syncthreads();
 		HSTAMP(1); // stage
 
-		// ---- first pass: run up through image subsequence tid from its first bit, then the own
-		// subsequence tid + 1 with symbols (a read's first tile starts exactly at its bit 0)
+		// ---- first pass: run up through image subsequence tid from its first bit (no output), then the
+		// own subsequence tid + 1 with symbols (a read's first tile starts exactly at its bit 0).
+		// Two loops rather than one with a mode per lane: each is leaner than the fused form.
 		{
-			uint32_t c, f;
+			uint32_t c, c0;
 			const bool exact = t == 0 && tid == 0;
-			const uint32_t e = huff_run<true, true>(lbits, lut, lut2, l2off, l2bits, a.huff, exact ? S : tid * S, (tid + 1) * S,
-								(tid + 2) * S, nbits, c, slots + tid * HSLOT, f);
+			uint32_t f = S;
+			if (!__all(exact)) {
+				f = huff_run<false>(lbits, lut, lut2, l2off, l2bits, a.huff, tid * S, (tid + 1) * S, nbits, c0, nullptr);
+				if (f == HEND && (tid + 1) * S < nbits)
+					f = (tid + 1) * S; // a guess that ran into a bit pattern that is no code: any guess will do
+				if (exact)
+					f = S;
+			}
+			const uint32_t e = huff_run<true>(lbits, lut, lut2, l2off, l2bits, a.huff, f, (tid + 2) * S, nbits, c,
+							  slots + tid * HSLOT);
 			sS[tid] = (uint8_t) (f == HEND ? ST_END : f - (tid + 1) * S);
 			sE[tid + 1] = (e == HEND ? PE_END : e) | (c << 24);
 			if (tid == 0)
