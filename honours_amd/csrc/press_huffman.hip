@@ -240,7 +240,7 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 {
 #ifdef HUF_DEBUG
 	unsigned long long stamp_ = clock64();
-	unsigned long long acc_[12] = { 0 };
+	unsigned long long acc_[16] = { 0 };
 #endif
 	constexpr int HT = HUF_HT;
 	__shared__ uint32_t lut[1 << HUF_LUT_BITS];
@@ -308,6 +308,7 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 				lst[idx] = (uint16_t) (tid | ((code & 31u) << 9) | ((pe & PE_END) ? (1u << 14) : 0u));
 			}
 			__syncthreads();
+			HSTAMP(12); // detection
 			const uint32_t nch = lst_n[par];
 			if (nch == 0) {
 				uint32_t before = 0;
@@ -331,14 +332,19 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 				const bool end = (ent >> 14) & 1u;
 				const uint32_t rel = (ent >> 9) & 31u;
 				uint32_t c;
+				// the whole workgroup waits for this wave: let it win the issue arbitration against the
+				// first-pass waves of the other workgroups on its SIMD
+				__builtin_amdgcn_s_setprio(3);
 				const uint32_t e = huff_run<true>(lbits, lut, lut2, l2off, l2bits, a.huff, end ? HEND : (u + 1) * S + rel,
 								  (u + 2) * S, nbits, c, slots + u * HSLOT);
+				__builtin_amdgcn_s_setprio(0);
 				if (mine) {
 					sS[u] = (uint8_t) (end ? ST_END : rel);
 					sE[u + 1] = (e == HEND ? PE_END : e) | (c << 24);
 				}
 			}
 			__syncthreads(); // counts settled before the next round's scan
+			HSTAMP(13); // re-decode
 		}
 	};
 
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) /
 	}
 #ifdef HUF_DEBUG
 	if (threadIdx.x == 0)
-		for (int i = 0; i < 12; i++)
+		for (int i = 0; i < 16; i++)
 			atomicAdd(&g_hufdbg[i], acc_[i]);
 #endif
 }
