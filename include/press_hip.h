@@ -2,7 +2,7 @@
  * press_hip.h - C ABI of libpress_hip.so: the MI355X (gfx950) implementation of the
  * per-read transform -> pack -> entropy hot path of sashajenner/honours `press/`.
  *
- * Two groups of entry points:
+ * Three groups of entry points:
  *
  *  (1) DROP-IN SYMBOLS.  Exactly the X_bound / X_press / X_depress triples that
  *      press/press.h declares for the hot-path methods (file:line cited on each),
@@ -17,6 +17,11 @@
  *      with device-resident buffers - the throughput path (one read per call is
  *      launch/PCIe-latency bound).  Reads are independent (thesis/probspace/
  *      focus.tex:177-183), so a batch is the natural device unit.
+ *
+ *  (3) BLOW5 FILES (press_hip_blow5_*, slow5_svb_zd_*).  The data format on the input
+ *      side of the path: slow5lib's "svb-zd" signal codec on the
+ *      device and a host reader / writer for the record framing, so that signals
+ *      travel to and from the GPU as stored.
  *
  * Plain C: pointers and sizes only, no C++ or torch types.
  * Deviation from the reference, on purpose: X_press never writes past the capacity
@@ -246,7 +251,7 @@ int press_hip_kernel_times(int which, float *ms, int max);
 /* release every device and host resource held by the library */
 void press_hip_shutdown(void);
 
-/* ======================================================================= (3) BLOW5 input (host) */
+/* ======================================================================= (3) BLOW5 files (host) */
 
 /*
  * Reader for BLOW5 files that hands out the signal fields AS STORED: what the
