@@ -80,7 +80,7 @@ struct Ctx {
 	hipStream_t user = nullptr;
 	bool use_user = false;
 	// scratch shared by both modes
-	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, hgran, gran2;
+	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, hgran, cbits;
 	int use_v1 = -1; // PRESS_HIP_V1=1 selects the one-workgroup-per-read svb kernels (A/B)
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn;
@@ -326,7 +326,7 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 			return PRESS_HIP_EHIP;
 		if (!decode && is_shuff(method)) {
 			const size_t mc = max_chunks_of(total_samples, nreads);
-			if (g.gran2.reserve(mc * sizeof(uint64_t)))
+			if (g.cbits.reserve(mc * sizeof(ChunkBits)))
 				return PRESS_HIP_EHIP;
 		}
 		if (decode && is_shuff(method)) {
@@ -450,7 +450,7 @@ extern "C" void press_hip_shutdown(void)
 		return;
 	(void) hipSetDevice(g.device);
 	(void) hipStreamSynchronize(g.own);
-	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.chunks, &g.gran, &g.ctl, &g.first_chunk, &g.htiles, &g.hgran, &g.gran2, &g.sig, &g.off, &g.nsamp,
+	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.chunks, &g.gran, &g.ctl, &g.first_chunk, &g.htiles, &g.hgran, &g.cbits, &g.sig, &g.off, &g.nsamp,
 			  &g.arena, &g.arena_off, &g.lens, &g.lens2, &g.outn };
 	for (DevBuf *b : all)
 		b->release();
@@ -588,7 +588,7 @@ extern "C" int press_hip_press_batch(int method, const int16_t *sig, const uint6
 	a.ctl = (ChunkCtl *) g.ctl.p;
 	a.max_chunks = max_chunks_of(total_samples, nreads);
 	if (is_shuff(method))
-		a.gran2 = (uint64_t *) g.gran2.p;
+		a.cbits = (ChunkBits *) g.cbits.p;
 	a.first_chunk = (uint32_t *) g.first_chunk.p;
 
 	if (device_resident) {

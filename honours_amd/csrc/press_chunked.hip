@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 						    uint32_t nreads, ChunkDesc *chunks, uint64_t *gran,
 						    ChunkCtl *ctl, uint32_t max_chunks, uint64_t *out_len,
 						    uint32_t *out_n, uint32_t *first_chunk, ReadMeta *meta = nullptr,
-						    uint64_t *gran2 = nullptr, const uint8_t *in = nullptr, uint32_t hdr = 0)
+						    const uint8_t *in = nullptr, uint32_t hdr = 0)
 {
 	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
 	uint32_t n = 0, nch = 0;
@@ -246,8 +246,6 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 		d.kmask[0] = d.kmask[1] = d.kmask[2] = d.kmask[3] = 0;
 		chunks[first + j] = d;
 		gran[first + j] = 0;
-		if (gran2)
-			gran2[first + j] = 0;
 	}
 }
 
@@ -1146,6 +1144,17 @@ __device__ __forceinline__ uint4 sub_zd(uint4 raw, uint32_t n, uint32_t i0, uint
 	return make_uint4(zz[0], zz[1], zz[2], zz[3]);
 }
 
+// which of a lane's 8 samples starting at i0 are one-byte values: inside [1, n), no exception
+__device__ __forceinline__ uint32_t low_mask(const uint4 &z, uint32_t i0, uint32_t n)
+{
+	uint32_t lowm = i0 + 8 <= n ? 0xFFu : (i0 < n ? (1u << (n - i0)) - 1u : 0u);
+	if (i0 == 0)
+		lowm &= ~1u;
+	if ((z.x | z.y | z.z | z.w) & 0xFF00FF00u)
+		lowm &= ~exc_mask(z, i0);
+	return lowm;
+}
+
 // ex-zd: does any read of the batch need the second scan (all samples divisible by 2^q, q > 0)?
 __global__ __launch_bounds__(256) void k_ex_redo_flag(BatchArgs a)
 {
@@ -1158,9 +1167,12 @@ __global__ __launch_bounds__(256) void k_ex_redo_flag(BatchArgs a)
 // in flight per wave) and leaves, per wave quarter, the number of exceptions and the sub-tiles that
 // hold one in the chunk descriptor; k_ex_prefix turns the counts into ranks and k_ex_list
 // writes the (few) exceptions at their final rank from the flagged sub-tiles alone.
-template <bool REDO>
+// HUFF: also the number of Huffman code bits of every wave quarter (ChunkBits), which lets
+// k_huff_encode_chunked place its bits without any chain either.
+template <bool REDO, bool HUFF = false>
 __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 {
+	__shared__ uint8_t s_len[HUFF ? 256 : 4];
 	if (REDO && uni(a.ctl->pad0[0]) == 0)
 		return; // no read of this batch has q > 0 (the common case)
 	const uint32_t t = blockIdx.x;
@@ -1168,6 +1180,10 @@ __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 		return;
 	const int lane = threadIdx.x & 63;
 	const int w = (int) uni(threadIdx.x >> 6);
+	if (HUFF) {
+		s_len[threadIdx.x] = (uint8_t) (a.huff->enc[threadIdx.x] >> 24);
+		__syncthreads();
+	}
 	ChunkDesc *dp = a.chunks + t;
 	const ChunkU d = load_chunk(dp);
 	const uint32_t n = d.n;
@@ -1184,10 +1200,13 @@ __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 	}
 	const int16_t *in = a.sig + d.sig_off;
 	const uint32_t ws = first + w * WAVE_SAMPLES;
-	if (ws >= n)
-		return; // the descriptor's counts are zero already
+	if (ws >= n) { // the descriptor's counts are zero already
+		if (HUFF && lane == 0)
+			a.cbits[t].q[w] = 0;
+		return;
+	}
 
-	uint32_t kmask = 0, etot = 0, ored32 = 0, zd0 = 0;
+	uint32_t kmask = 0, etot = 0, ored32 = 0, zd0 = 0, lbits = 0;
 	uint32_t carry = 0; // the sample in front of the sub-tile
 	if (ws > 0)
 		carry = (uint32_t) (uint16_t) in[ws - 1] << 16;
@@ -1215,10 +1234,24 @@ __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 				const uint32_t inc = wave_incl_scan_dpp(__popc(exc_mask(z, i0)));
 				etot += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
 			}
+			if (HUFF) { // code lengths of the one-byte values: samples [1, n) that are no exceptions
+				const uint32_t lowm = low_mask(z, i0, n);
+				const uint32_t zz[4] = { z.x, z.y, z.z, z.w };
+#pragma unroll
+				for (int h = 0; h < 8; h++) {
+					const uint32_t l = s_len[(zz[h >> 1] >> (16 * (h & 1))) & 0xFFu];
+					lbits += ((lowm >> h) & 1u) ? l : 0u;
+				}
+			}
 		}
 #pragma unroll
 		for (int k = 0; k < 4; k++)
 			raw[k] = nxt[k];
+	}
+	if (HUFF) {
+		const uint32_t inc = wave_incl_scan_dpp(lbits);
+		if (lane == 63)
+			a.cbits[t].q[w] = inc;
 	}
 	if (!REDO) { // OR of the raw samples (qts), one atomic per wave
 		uint32_t o = (ored32 | (ored32 >> 16)) & 0xFFFFu;
@@ -1254,6 +1287,14 @@ __global__ __launch_bounds__(256) void k_ex_prefix(BatchArgs a, int exzd)
 		e += (uint64_t) dp[j].ecnt[0] + dp[j].ecnt[1] + dp[j].ecnt[2] + dp[j].ecnt[3];
 	}
 	m->nex = (uint32_t) e;
+	if (a.cbits) { // Huffman code bits in front of every chunk
+		ChunkBits *cb = a.cbits + a.first_chunk[r];
+		uint64_t b = 0;
+		for (uint32_t j = 0; j < nch; j++) {
+			cb[j].before = b;
+			b += (uint64_t) cb[j].q[0] + cb[j].q[1] + cb[j].q[2] + cb[j].q[3];
+		}
+	}
 	uint32_t q = 0;
 	if (exzd) { // ex_zd.c:358-381
 		const uint32_t ored = m->ored;
@@ -1371,14 +1412,12 @@ __global__ __launch_bounds__(CWG) void k_low_encode_chunked(BatchArgs a)
 }
 
 // Pass B, static-Huffman stream (huffman.c:1184 + do_memory_encode :848: the codes packed
-// from bit 0 of each byte upwards - a little-endian bit stream).  Chunks in ticket order by a
-// persistent grid; what chains the chunks of a read is the number of code BITS in front of a
-// chunk (decoupled look-back over a.gran2, as for the exception counts):
-//   phase 1  every lane adds up the code lengths of its 128 samples, the workgroup publishes
-//            the chunk's total and wave 0 looks back for the bits in front of the chunk;
-//   phase 2  the four waves are independent: a wave knows the bit position Bq of its quarter,
-//            stages the codes of one 512-sample sub-tile at a time in a private LDS buffer
-//            (LDS atomic OR of code << bitpos) and copies the completed dwords out.
+// from bit 0 of each byte upwards - a little-endian bit stream).  One workgroup per chunk in any
+// order, its four waves independent of each other: pass A has counted the code bits of every
+// wave quarter (k_ex_scan_chunked<.., true>) and k_ex_prefix has summed them, so a wave knows the
+// bit position Bq of its quarter from the start; it stages the codes of one 512-sample sub-tile
+// at a time in a private LDS buffer (LDS atomic OR of code << bitpos) and copies the completed
+// dwords out.  No ticket, no look-back, one barrier (the table load).
 // Who writes a byte shared by two quarters: the quarter that holds the byte's LAST bit; it
 // recomputes the few bits its predecessors put into that byte from the samples in front of
 // it.  The last, partial byte of a read and out_len are written by wave 0 of its last chunk.
@@ -1417,190 +1456,126 @@ __device__ __forceinline__ uint32_t huff_tail_bits(const int16_t *in, uint32_t e
 	return got >= nb ? (acc >> (got - nb)) & ((1u << nb) - 1u) : acc;
 }
 
-// which of a lane's 8 samples starting at i0 are one-byte values: inside [1, n), no exception
-__device__ __forceinline__ uint32_t low_mask(const uint4 &z, uint32_t i0, uint32_t n)
-{
-	uint32_t lowm = i0 + 8 <= n ? 0xFFu : (i0 < n ? (1u << (n - i0)) - 1u : 0u);
-	if (i0 == 0)
-		lowm &= ~1u;
-	if ((z.x | z.y | z.z | z.w) & 0xFF00FF00u)
-		lowm &= ~exc_mask(z, i0);
-	return lowm;
-}
 
 __global__ __launch_bounds__(CWG) void k_huff_encode_chunked(BatchArgs a)
 {
 	__shared__ uint32_t enc[256];
 	__shared__ uint32_t stg_all[4][HSTG];
-	__shared__ uint32_t s_ticket;
-	__shared__ uint32_t s_wbits[4];
-	__shared__ uint64_t s_before;
 
 	enc[threadIdx.x] = a.huff->enc[threadIdx.x];
 	for (uint32_t i = threadIdx.x; i < 4u * HSTG; i += CWG)
 		(&stg_all[0][0])[i] = 0;
-	const uint32_t nchunks = uni(a.ctl->nchunks);
+	__syncthreads(); // the only barrier
+	const uint32_t t = blockIdx.x;
+	if (t >= uni(a.ctl->nchunks))
+		return;
 	const int lane = threadIdx.x & 63;
 	const int w = (int) uni(threadIdx.x >> 6);
 	uint32_t *stg = stg_all[w];
-	for (;;) {
-		if (threadIdx.x == 0)
-			s_ticket = atomicAdd(&a.ctl->ticket2, 1u);
-		__syncthreads();
-		const uint32_t t = uni(s_ticket);
-		if (t >= nchunks)
-			break;
-		const ChunkDesc *dp = a.chunks + t;
-		const ChunkU d = load_chunk(dp);
-		const ReadMeta *m = a.meta + d.read;
-		if (uni(m->status)) { // out_len = FAILED was written by k_ex_section; none of the read's chunks looks back
-			__syncthreads();
-			continue;
-		}
-		const uint32_t n = d.n;
-		const uint32_t first = d.j * CHUNK;
-		const bool last = first + CHUNK >= n;
-		const uint32_t ws = first + w * WAVE_SAMPLES;
-		const int16_t *in = a.sig + d.sig_off;
-		const uint32_t head = uni(m->hdr) + uni(m->seclen) + 4; // bytes in front of the payload
-		uint8_t *payload = a.out + d.out_base + head;
-		const uint64_t cap = uni64(a.out_off[d.read + 1]) - d.out_base;
-		uint32_t carry0 = 0; // the sample in front of the quarter
-		if (ws > 0 && ws < n)
-			carry0 = (uint32_t) (uint16_t) in[ws - 1] << 16;
-
-		// ---- phase 1: code bits of the quarter; the samples stream through, four sub-tiles in flight
-		uint32_t lbits = 0;
-		{
-			uint32_t carry = carry0;
-			uint4 raw[4];
-#pragma unroll
-			for (int k = 0; k < 4; k++)
-				raw[k] = sub_load(in, n, ws + k * SUB + lane * 8);
-#pragma unroll 1
-			for (int kk = 0; kk < CK; kk += 4) {
-				uint4 nxt[4];
-#pragma unroll
-				for (int k = 0; k < 4; k++)
-					nxt[k] = kk + 4 + k < CK ? sub_load(in, n, ws + (kk + 4 + k) * SUB + lane * 8) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const uint32_t i0 = ws + (kk + k) * SUB + lane * 8;
-					const uint4 z = sub_zd(raw[k], n, i0, carry);
-					const uint32_t lowm = low_mask(z, i0, n);
-					const uint32_t zz[4] = { z.x, z.y, z.z, z.w };
-#pragma unroll
-					for (int h = 0; h < 8; h++) {
-						const uint32_t l = enc[(zz[h >> 1] >> (16 * (h & 1))) & 0xFFu] >> 24;
-						lbits += ((lowm >> h) & 1u) ? l : 0u;
-					}
-				}
-#pragma unroll
-				for (int k = 0; k < 4; k++)
-					raw[k] = nxt[k];
-			}
-		}
-		{
-			const uint32_t inc = wave_incl_scan_dpp(lbits);
-			if (lane == 63)
-				s_wbits[w] = inc;
-		}
-		__syncthreads();
-		const uint32_t q0 = uni(s_wbits[0]), q1 = uni(s_wbits[1]), q2 = uni(s_wbits[2]), q3 = uni(s_wbits[3]);
-		if (w == 0) {
-			const uint64_t before = lookback(a.gran2, t, d.j, (uint64_t) q0 + q1 + q2 + q3, last);
+	const ChunkDesc *dp = a.chunks + t;
+	const ChunkU d = load_chunk(dp);
+	const ReadMeta *m = a.meta + d.read;
+	if (uni(m->status))
+		return; // out_len = FAILED was written by k_ex_section
+	const uint32_t n = d.n;
+	const uint32_t first = d.j * CHUNK;
+	const bool last = first + CHUNK >= n;
+	const uint32_t ws = first + w * WAVE_SAMPLES;
+	const int16_t *in = a.sig + d.sig_off;
+	const uint32_t head = uni(m->hdr) + uni(m->seclen) + 4; // bytes in front of the payload
+	uint8_t *payload = a.out + d.out_base + head;
+	const uint64_t cap = uni64(a.out_off[d.read + 1]) - d.out_base;
+	// code bits of the quarters and in front of the chunk: k_ex_scan_chunked<.., true> + k_ex_prefix
+	const ChunkBits *cb = a.cbits + t;
+	const uint32_t q0 = uni(cb->q[0]), q1 = uni(cb->q[1]), q2 = uni(cb->q[2]), q3 = uni(cb->q[3]);
+	const uint64_t before = uni64(cb->before);
+	if (w == 0 && last) { // the read ends here: its length and its last, partial byte (zero padded, huffman.c:878)
+		const uint64_t bits = before + q0 + q1 + q2 + q3;
+		const uint64_t total = (uint64_t) head + (bits + 7) / 8;
+		const uint32_t nbt = (uint32_t) bits & 7u;
+		if (total <= cap && nbt) {
+			const uint32_t tb = huff_tail_bits(in, n, nbt, enc, lane);
 			if (lane == 0)
-				s_before = before;
-			if (last) { // the read ends here: its length and its last, partial byte (zero padded, huffman.c:878)
-				const uint64_t bits = before + q0 + q1 + q2 + q3;
-				const uint64_t total = (uint64_t) head + (bits + 7) / 8;
-				const uint32_t nbt = (uint32_t) bits & 7u;
-				if (total <= cap && nbt) {
-					const uint32_t tb = huff_tail_bits(in, n, nbt, enc, lane);
-					if (lane == 0)
-						payload[bits >> 3] = (uint8_t) tb;
-				}
-				if (lane == 0)
-					a.out_len[d.read] = total <= cap ? total : CFAIL64;
-			}
+				payload[bits >> 3] = (uint8_t) tb;
 		}
-		__syncthreads();
-		const uint32_t mybits = w == 0 ? q0 : w == 1 ? q1 : w == 2 ? q2 : q3;
-		const uint64_t Bq = uni64(s_before) + (w > 0 ? q0 : 0u) + (w > 1 ? q1 : 0u) + (w > 2 ? q2 : 0u);
-		// ---- phase 2: the samples again (from L2); a quarter that would run past the slot writes
-		// nothing - the read fails
-		if (mybits && (uint64_t) head + (Bq + mybits + 7) / 8 <= cap) {
-			// the nb bits in front of Bq that share its byte
-			const uint32_t nb = (uint32_t) Bq & 7u;
-			if (nb) {
-				const uint32_t tb = huff_tail_bits(in, ws, nb, enc, lane);
-				if (lane == 0)
-					stg[0] = tb;
-			}
-			uint8_t *g = payload + (Bq >> 3); // byte of staging bit 0
-			uint32_t fill = nb;               // bits waiting at the front of the staging buffer
-			wave_lds_sync();
-			uint32_t carry = carry0;
-			uint4 raw = sub_load(in, n, ws + lane * 8);
+		if (lane == 0)
+			a.out_len[d.read] = total <= cap ? total : CFAIL64;
+	}
+	const uint32_t mybits = w == 0 ? q0 : w == 1 ? q1 : w == 2 ? q2 : q3;
+	const uint64_t Bq = before + (w > 0 ? q0 : 0u) + (w > 1 ? q1 : 0u) + (w > 2 ? q2 : 0u);
+	// a quarter that would run past the slot writes nothing - the read fails
+	if (ws >= n || !mybits || (uint64_t) head + (Bq + mybits + 7) / 8 > cap)
+		return;
+	// the nb bits in front of Bq that share its byte
+	const uint32_t nb = (uint32_t) Bq & 7u;
+	if (nb) {
+		const uint32_t tb = huff_tail_bits(in, ws, nb, enc, lane);
+		if (lane == 0)
+			stg[0] = tb;
+	}
+	uint8_t *g = payload + (Bq >> 3); // byte of staging bit 0
+	uint32_t fill = nb;               // bits waiting at the front of the staging buffer
+	wave_lds_sync();
+	uint32_t carry = ws > 0 ? (uint32_t) (uint16_t) in[ws - 1] << 16 : 0u; // the sample in front of the sub-tile
+	uint4 raw[2];
+	raw[0] = sub_load(in, n, ws + lane * 8);
+	raw[1] = sub_load(in, n, ws + SUB + lane * 8);
 #pragma unroll 1
-			for (int k = 0; k < CK; k++) {
-				const uint32_t sub0 = ws + k * SUB;
-				if (sub0 >= n)
-					break;
-				const uint32_t i0 = sub0 + lane * 8;
-				const uint4 nxt = k + 1 < CK ? sub_load(in, n, i0 + SUB) : make_uint4(0, 0, 0, 0);
-				const uint4 z = sub_zd(raw, n, i0, carry);
-				raw = nxt;
-				const uint32_t lowm = low_mask(z, i0, n);
-				const uint32_t zz[4] = { z.x, z.y, z.z, z.w };
-				uint32_t e[8];
-				uint32_t lb = 0;
+	for (int k = 0; k < CK; k++) {
+		const uint32_t sub0 = ws + k * SUB;
+		if (sub0 >= n)
+			break;
+		const uint32_t i0 = sub0 + lane * 8;
+		const uint4 nxt = k + 2 < CK ? sub_load(in, n, i0 + 2 * SUB) : make_uint4(0, 0, 0, 0);
+		const uint4 z = sub_zd(raw[0], n, i0, carry);
+		raw[0] = raw[1];
+		raw[1] = nxt;
+		const uint32_t lowm = low_mask(z, i0, n);
+		const uint32_t zz[4] = { z.x, z.y, z.z, z.w };
+		uint32_t e[8];
+		uint32_t lb = 0;
 #pragma unroll
-				for (int h = 0; h < 8; h++) {
-					e[h] = enc[(zz[h >> 1] >> (16 * (h & 1))) & 0xFFu];
-					lb += ((lowm >> h) & 1u) ? (e[h] >> 24) : 0u;
-				}
-				const uint32_t inc = wave_incl_scan_dpp(lb);
-				const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
-				uint32_t pos = fill + inc - lb;
+		for (int h = 0; h < 8; h++) {
+			e[h] = enc[(zz[h >> 1] >> (16 * (h & 1))) & 0xFFu];
+			lb += ((lowm >> h) & 1u) ? (e[h] >> 24) : 0u;
+		}
+		const uint32_t inc = wave_incl_scan_dpp(lb);
+		const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+		uint32_t pos = fill + inc - lb;
 #pragma unroll
-				for (int h = 0; h < 8; h++) {
-					if ((lowm >> h) & 1u) {
-						const uint64_t wv = (uint64_t) (e[h] & 0xFFFFFFu) << (pos & 31u);
-						if ((uint32_t) wv)
-							atomicOr(&stg[pos >> 5], (uint32_t) wv);
-						if ((uint32_t) (wv >> 32))
-							atomicOr(&stg[(pos >> 5) + 1], (uint32_t) (wv >> 32));
-						pos += e[h] >> 24;
-					}
-				}
-				wave_lds_sync();
-				// completed dwords out (unaligned 4-byte stores), the partial one to the front
-				const uint32_t total = fill + tot;
-				const uint32_t nfull = total >> 5;
-				for (uint32_t c = (uint32_t) lane; c < nfull; c += 64) {
-					const uint32_t v = stg[c];
-					stg[c] = 0;
-					__builtin_memcpy(g + 4ull * c, &v, 4);
-				}
-				if (nfull && lane == 0) {
-					const uint32_t tl = stg[nfull];
-					stg[nfull] = 0;
-					stg[0] = tl;
-				}
-				g += 4ull * nfull;
-				fill = total & 31u;
-				wave_lds_sync();
-			}
-			// whole bytes that are left; a partial last byte belongs to whoever holds its last bit
-			if (lane == 0) {
-				const uint32_t v = stg[0];
-				for (uint32_t b = 0; b < (fill >> 3); b++)
-					g[b] = (uint8_t) (v >> (8 * b));
-				stg[0] = 0;
+		for (int h = 0; h < 8; h++) {
+			if ((lowm >> h) & 1u) {
+				const uint64_t wv = (uint64_t) (e[h] & 0xFFFFFFu) << (pos & 31u);
+				if ((uint32_t) wv)
+					atomicOr(&stg[pos >> 5], (uint32_t) wv);
+				if ((uint32_t) (wv >> 32))
+					atomicOr(&stg[(pos >> 5) + 1], (uint32_t) (wv >> 32));
+				pos += e[h] >> 24;
 			}
 		}
-		__syncthreads(); // every wave has read s_ticket / s_before / s_wbits before they are overwritten
+		wave_lds_sync();
+		// completed dwords out (unaligned 4-byte stores), the partial one to the front
+		const uint32_t total = fill + tot;
+		const uint32_t nfull = total >> 5;
+		for (uint32_t c = (uint32_t) lane; c < nfull; c += 64) {
+			const uint32_t v = stg[c];
+			stg[c] = 0;
+			__builtin_memcpy(g + 4ull * c, &v, 4);
+		}
+		if (nfull && lane == 0) {
+			const uint32_t tl = stg[nfull];
+			stg[nfull] = 0;
+			stg[0] = tl;
+		}
+		g += 4ull * nfull;
+		fill = total & 31u;
+		wave_lds_sync();
+	}
+	// whole bytes that are left; a partial last byte belongs to whoever holds its last bit
+	if (lane == 0) {
+		const uint32_t v = stg[0];
+		for (uint32_t b = 0; b < (fill >> 3); b++)
+			g[b] = (uint8_t) (v >> (8 * b));
 	}
 }
 
@@ -1946,7 +1921,7 @@ static void run_encode(const BatchArgs &a, hipStream_t s)
 	hipLaunchKernelGGL((k_chunk_prep<false, KEY2>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
 			   a.nsamp, a.out_off, (const uint64_t *) nullptr, a.nreads, a.chunks, a.gran, a.ctl,
 			   a.max_chunks, a.out_len, (uint32_t *) nullptr, (uint32_t *) nullptr, (ReadMeta *) nullptr,
-			   (uint64_t *) nullptr, (const uint8_t *) nullptr, S5 ? 4u : 0u);
+			   (const uint8_t *) nullptr, S5 ? 4u : 0u);
 	// persistent grid: enough workgroups to fill the chip twice over (4 resident per CU)
 	const uint32_t grid = a.max_chunks < PERSISTENT_GRID ? a.max_chunks : PERSISTENT_GRID;
 	ktime_begin(0, s);
@@ -1974,7 +1949,7 @@ static void run_decode(const DecodeArgs &a, hipStream_t s)
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL((k_chunk_prep<true, KEY2>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
 			   a.nsamp, a.in_off, a.in_len, a.nreads, a.chunks, a.gran, a.ctl, a.max_chunks,
-			   (uint64_t *) nullptr, a.out_n, a.first_chunk, (ReadMeta *) nullptr, (uint64_t *) nullptr, a.in,
+			   (uint64_t *) nullptr, a.out_n, a.first_chunk, (ReadMeta *) nullptr, a.in,
 			   S5 ? 4u : 0u);
 	// surplus workgroups (max_chunks bounds the real count from above) exit at once
 	hipLaunchKernelGGL((k_svb_keyscan<KEY2, S5>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
@@ -1989,13 +1964,15 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_
 {
 	if (!a.nreads || !a.max_chunks)
 		return;
-	const uint32_t grid = a.max_chunks < PERSISTENT_GRID ? a.max_chunks : PERSISTENT_GRID;
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL((k_chunk_prep<false, false>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
 			   a.nsamp, a.out_off, (const uint64_t *) nullptr, a.nreads, a.chunks, a.gran, a.ctl,
-			   a.max_chunks, a.out_len, (uint32_t *) nullptr, a.first_chunk, a.meta, huff ? a.gran2 : nullptr);
+			   a.max_chunks, a.out_len, (uint32_t *) nullptr, a.first_chunk, a.meta);
 	// surplus workgroups (max_chunks bounds the real count from above) exit at once
-	hipLaunchKernelGGL((k_ex_scan_chunked<false>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
+	if (huff)
+		hipLaunchKernelGGL((k_ex_scan_chunked<false, true>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
+	else
+		hipLaunchKernelGGL((k_ex_scan_chunked<false>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	if (fmt == EXF_EXZD) {
 		// second scan on the shifted samples for reads with q > 0
 		hipLaunchKernelGGL(k_ex_redo_flag, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a);
@@ -2006,7 +1983,7 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_
 	launch_ex_section(a, fmt, huff, s);
 	ktime_begin(0, s);
 	if (huff)
-		hipLaunchKernelGGL(k_huff_encode_chunked, dim3(grid), dim3(CWG), 0, s, a);
+		hipLaunchKernelGGL(k_huff_encode_chunked, dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	else
 		hipLaunchKernelGGL(k_low_encode_chunked, dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	ktime_end(0, s);

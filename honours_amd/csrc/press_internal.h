@@ -72,6 +72,11 @@ struct ChunkDesc {                          // written by k_chunk_prep, one per 
 	uint16_t kmask[4];  // per wave: sub-tiles that are not plain (exception or ragged tail)
 };
 static_assert(sizeof(ChunkDesc) == 64, "ChunkDesc is one 64-byte line");
+struct ChunkBits {                          // Huffman encode: code bits of a chunk (k_ex_scan_chunked<.., true>, k_ex_prefix)
+	uint64_t before;    // bits of the read's payload in front of this chunk
+	uint32_t q[4];      // bits of each wave's quarter
+	uint32_t pad[2];
+};
 struct ChunkCtl {                           // device control block; every word on its own 128-B line
 	uint32_t ticket;    // next chunk to hand out (atomic)
 	uint32_t pad0[31];
@@ -99,7 +104,7 @@ struct BatchArgs {
 	uint64_t *gran;           // [max_chunks] look-back granules (zeroed per launch)
 	ChunkCtl *ctl;            // zeroed per launch
 	uint32_t max_chunks;      // >= sum over reads of ceil(n / CHUNK)
-	uint64_t *gran2;          // [max_chunks] look-back granules of the Huffman bit-count chain
+	ChunkBits *cbits;         // [max_chunks] Huffman code-bit counts (NULL for the other methods)
 	uint32_t *first_chunk;    // [nreads] id of the first chunk of read r (exception-split encode)
 };
 
