@@ -334,3 +334,26 @@ def test_huffman_truncated_payload(oracle):
         assert (rg == 0) == (ro == 0), (cut, rg, ro)
         if ro == 0:
             assert bg.size == bo.size and np.array_equal(bg, bo), (cut, bg.size, bo.size)
+
+
+def test_longest_read_in_a_mixed_batch(oracle):
+    """a read of NA12878's maximum length (5.7 M samples: 175 chunks, ~420 Huffman tiles - deep
+    look-back chains) next to tiny reads in ONE batch call, byte parity with the oracle for the
+    chunked kernel families"""
+    n_big, first = 5_724_000, 470
+    big = synth.synth_read(77, 3, n_big, first)
+    rng = np.random.default_rng(3)
+    small = [np.cumsum(rng.integers(-20, 21, size=n)).astype(np.int16) for n in (1, 2, 9, 513, 4097)]
+    reads = [small[0], big, small[1], small[2], big[:70001], small[3], small[4]]
+    for m in ("svb12_zd", "slow5_svb_zd", "hasgam_vbsse21_zdq", "shuffman_vbe21_zd"):
+        caps = [int(press.bound(m, len(r))) + 1024 for r in reads]
+        streams = press.press_batch_host(m, reads, caps=caps)
+        for r, st in zip(reads, streams):
+            if not shuff_ok(m, r):
+                continue
+            ret, want = oracle.press(m, r)
+            assert ret == 0 and st == want, (m, len(r))
+        ok = [(r, st) for r, st in zip(reads, streams) if st is not None and shuff_ok(m, r)]
+        back = press.depress_batch_host(m, [st for _, st in ok], [len(r) for r, _ in ok])
+        for (r, _), b in zip(ok, back):
+            assert b is not None and np.array_equal(b, r), (m, len(r))
