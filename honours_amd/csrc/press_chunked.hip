@@ -34,7 +34,10 @@ constexpr uint32_t SUB = 512;                // samples per sub-tile (64 lanes x
 constexpr uint32_t WAVE_SAMPLES = CK * SUB;  // 8192
 static_assert(WAVE_SAMPLES * 4 == CHUNK, "chunk = 4 waves");
 
-constexpr uint32_t PERSISTENT_GRID = 2048;   // workgroups of the ticket-loop kernels
+#ifndef PERSISTENT_GRID_N
+#define PERSISTENT_GRID_N 1024 // = what is resident (4 workgroups of ~110 VGPRs per CU); 768-1280 measured equal, 2048 2.5 % slower
+#endif
+constexpr uint32_t PERSISTENT_GRID = PERSISTENT_GRID_N;   // workgroups of the ticket-loop kernel (k_svb_encode_chunked)
 constexpr uint64_t G_A = 1ull << 62;         // granule: aggregate of this chunk only
 constexpr uint64_t G_P = 2ull << 62;         // granule: inclusive prefix up to this chunk
 constexpr uint64_t G_MASK = (1ull << 62) - 1;
@@ -1922,7 +1925,7 @@ static void run_encode(const BatchArgs &a, hipStream_t s)
 			   a.nsamp, a.out_off, (const uint64_t *) nullptr, a.nreads, a.chunks, a.gran, a.ctl,
 			   a.max_chunks, a.out_len, (uint32_t *) nullptr, (uint32_t *) nullptr, (ReadMeta *) nullptr,
 			   (const uint8_t *) nullptr, S5 ? 4u : 0u);
-	// persistent grid: enough workgroups to fill the chip twice over (4 resident per CU)
+	// persistent grid: as many workgroups as are resident (4 per CU)
 	const uint32_t grid = a.max_chunks < PERSISTENT_GRID ? a.max_chunks : PERSISTENT_GRID;
 	ktime_begin(0, s);
 	hipLaunchKernelGGL((k_svb_encode_chunked<KEY2, ZD, S5>), dim3(grid), dim3(CWG), 0, s, a);
