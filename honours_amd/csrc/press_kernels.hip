@@ -633,11 +633,7 @@ __global__ __launch_bounds__(64) void k_ex_section(BatchArgs a, int fmt, int huf
 	put32(p, nex);
 	p += 4;
 	if (fmt == EXF_VBE21) {
-		for (uint32_t k = 0; k < nex; k++)
-			put32(p + 4 * k, pos[k]);
-		p += 4ull * nex;
-		for (uint32_t k = 0; k < nex; k++)
-			put16(p + 2 * k, val[k]);
+		// nex x u32 positions, nex x u16 values: copied by k_ex_fill_vbe21, a whole wave per read
 	} else if (nex == 1) {
 		put32(p, pos[0]);
 		if (fmt == EXF_EXZD)
@@ -673,6 +669,26 @@ __global__ __launch_bounds__(64) void k_ex_section(BatchArgs a, int fmt, int huf
 	m->status = 0;
 	if (!huff)
 		a.out_len[r] = (uint64_t) hdr + seclen + nlow; // the Huffman pass B knows its own length
+}
+
+// vbe21's exception section (press.c:2703-2715: nex x u32 position, nex x u16 raw value) is a
+// plain copy of the lists: one wave per read instead of k_ex_section's single lane, so that a
+// read with thousands of exceptions costs microseconds, not milliseconds.
+__global__ __launch_bounds__(64) void k_ex_fill_vbe21(BatchArgs a)
+{
+	const uint32_t r = blockIdx.x;
+	const ReadMeta *m = a.meta + r;
+	if (m->status)
+		return;
+	const uint32_t nex = m->nex;
+	const uint64_t o0 = a.off[r];
+	const uint32_t *pos = a.ex_pos + o0;
+	const uint32_t *val = a.ex_val + o0;
+	uint8_t *p = a.out + a.out_off[r] + m->hdr + 4;
+	for (uint32_t k = threadIdx.x; k < nex; k += 64) {
+		put32(p + 4ull * k, pos[k]);
+		put16(p + 4ull * nex + 2ull * k, val[k]);
+	}
 }
 
 // ------------------------------------------------------------------ exception split: pass B (one-byte stream)
@@ -923,10 +939,7 @@ __global__ __launch_bounds__(64) void k_ex_parse(DecodeArgs a, int fmt, int huff
 	} else if (fmt == EXF_VBE21) {
 		if (left < 6ull * nex)
 			return;
-		for (uint32_t k = 0; k < nex; k++) {
-			pos[k] = get32(p + 4 * k);
-			val[k] = get16(p + 4ull * nex + 2 * k);
-		}
+		// the lists themselves: k_ex_parse_fill_vbe21, a whole wave per read
 		seclen += 6ull * nex;
 	} else if (nex == 1) {
 		const uint32_t need = (fmt == EXF_EXZD) ? 8u : 6u;
@@ -965,9 +978,11 @@ __global__ __launch_bounds__(64) void k_ex_parse(DecodeArgs a, int fmt, int huff
 		seclen += 8ull + lp + lv;
 	}
 	// positions must be strictly increasing and inside zd[1..cap)
-	for (uint32_t k = 0; k < nex; k++) {
-		if (pos[k] >= cap - 1 || (k && pos[k] <= pos[k - 1]))
-			return;
+	if (fmt != EXF_VBE21) {
+		for (uint32_t k = 0; k < nex; k++) {
+			if (pos[k] >= cap - 1 || (k && pos[k] <= pos[k - 1]))
+				return;
+		}
 	}
 	m->nex = nex;
 	m->seclen = (uint32_t) seclen;
@@ -986,6 +1001,32 @@ __global__ __launch_bounds__(64) void k_ex_parse(DecodeArgs a, int fmt, int huff
 		return;
 	m->nlow = (uint32_t) nlow;
 	m->status = 0;
+}
+
+// vbe21: exception lists out of the section and their validation (strictly increasing positions
+// inside zd[1..cap)), one wave per read; a violation fails the read like k_ex_parse would.
+__global__ __launch_bounds__(64) void k_ex_parse_fill_vbe21(DecodeArgs a)
+{
+	const uint32_t r = blockIdx.x;
+	ReadMeta *m = a.meta + r;
+	if (m->status)
+		return;
+	const uint32_t nex = m->nex;
+	const uint32_t cap = a.nsamp[r];
+	const uint64_t o0 = a.off[r];
+	uint32_t *pos = a.ex_pos + o0;
+	uint32_t *val = a.ex_val + o0;
+	const uint8_t *p = a.in + a.in_off[r] + m->hdr + 4;
+	bool bad = false;
+	for (uint32_t k = threadIdx.x; k < nex; k += 64) {
+		const uint32_t pk = get32(p + 4ull * k);
+		pos[k] = pk;
+		val[k] = get16(p + 4ull * nex + 2ull * k);
+		if (pk >= cap - 1 || (k && pk <= get32(p + 4ull * (k - 1))))
+			bad = true;
+	}
+	if (__ballot(bad) && threadIdx.x == 0)
+		m->status = 1;
 }
 
 // ------------------------------------------------------------------ decode: merge + undo zig-zag delta
@@ -1126,6 +1167,8 @@ void launch_svb_decode(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s
 void launch_ex_section(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_ex_section, dim3(a.nreads), dim3(64), 0, s, a, fmt, huff ? 2 : 0);
+	if (fmt == EXF_VBE21)
+		hipLaunchKernelGGL(k_ex_fill_vbe21, dim3(a.nreads), dim3(64), 0, s, a);
 }
 
 void launch_ex_encode(const BatchArgs &a0, int fmt, bool huff, hipStream_t s)
@@ -1138,6 +1181,8 @@ void launch_ex_encode(const BatchArgs &a0, int fmt, bool huff, hipStream_t s)
 	if (fmt == EXF_EXZD)
 		hipLaunchKernelGGL((k_ex_scan<true>), grid, dim3(WG), 0, s, a);
 	hipLaunchKernelGGL(k_ex_section, grid, dim3(64), 0, s, a, fmt, huff ? 1 : 0);
+	if (fmt == EXF_VBE21)
+		hipLaunchKernelGGL(k_ex_fill_vbe21, grid, dim3(64), 0, s, a);
 	ktime_begin(0, s);
 	if (huff)
 		hipLaunchKernelGGL((k_low_encode<true>), grid, dim3(WG), 0, s, a);
@@ -1151,6 +1196,8 @@ void launch_ex_encode(const BatchArgs &a0, int fmt, bool huff, hipStream_t s)
 void launch_ex_parse_huff(const DecodeArgs &a, int fmt, bool huff, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_ex_parse, dim3(a.nreads), dim3(64), 0, s, a, fmt, huff ? 1 : 0);
+	if (fmt == EXF_VBE21)
+		hipLaunchKernelGGL(k_ex_parse_fill_vbe21, dim3(a.nreads), dim3(64), 0, s, a);
 	if (huff) {
 		ktime_begin(1, s);
 		launch_huff_decode(a, s);
