@@ -1586,7 +1586,7 @@ __global__ __launch_bounds__(CWG) void k_huff_encode_chunked(BatchArgs a)
 //
 // Second half of vbe21_depress and siblings (press.c:2757-2771) fused with unzigdelta_u16_16
 // (trans.c:260), after k_ex_parse has produced the sorted exception list (and, for the
-// Huffman variants, k_huff_decode_par the one-byte stream).  Sample i >= 1 is exception e
+// Huffman variants, k_huff_decode_tiles the one-byte stream).  Sample i >= 1 is exception e
 // if pos[e] == i-1, otherwise one-byte value number (i-1) - #exceptions before it; so a
 // chunk finds its place in the stream by binary search - only the running sample value
 // needs the look-back chain.

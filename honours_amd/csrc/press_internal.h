@@ -82,7 +82,7 @@ struct ChunkCtl {                           // device control block; every word 
 	uint32_t pad0[31];
 	uint32_t nchunks;   // written by k_chunk_prep, read by every workgroup
 	uint32_t pad1[31];
-	uint32_t ticket2;   // second ticket (decode)
+	uint32_t ticket2;   // spare second ticket
 	uint32_t pad2[31];
 };
 
