@@ -171,6 +171,23 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v)
 	return v;
 }
 
+#ifdef HUF_DEBUG
+__device__ unsigned long long g_hufdbg[16];
+extern "C" int press_hip_debug_huff(unsigned long long *dst)
+{
+	int rc = (int) hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_hufdbg), sizeof g_hufdbg);
+	unsigned long long z[16] = { 0 };
+	(void) hipMemcpyToSymbol(HIP_SYMBOL(g_hufdbg), z, sizeof z);
+	return rc;
+}
+// per-workgroup accumulation in registers, one atomicAdd per counter when the workgroup exits
+#define HSTAMP(i) do { const unsigned long long now_ = clock64(); acc_[i] += now_ - stamp_; stamp_ = now_; } while (0)
+#define HCOUNT(i, v) do { acc_[i] += (unsigned long long) (v); } while (0)
+#else
+#define HSTAMP(i) do { } while (0)
+#define HCOUNT(i, v) do { } while (0)
+#endif
+
 // Look-back of tile k (index t >= 1 in its read), executed by one wave.  my_s = the start
 // this tile's current result assumed.  Returns LB_DONE | codes in front of the tile once
 // the chain of aggregates is validated down to a prefix, or the predecessor's end position
@@ -215,26 +232,14 @@ __device__ __forceinline__ uint64_t tile_lookback(uint64_t *gran, uint32_t k, ui
 			need = (uint32_t) __shfl((int) gs, 63, 64);
 			done += 64;
 		}
+#ifdef HUF_DEBUG
+		if (lane == 0)
+			atomicAdd(&g_hufdbg[14], 1ull); // polls that found the chain incomplete
+#endif
 		__builtin_amdgcn_s_sleep(4);
 	}
 }
 
-#ifdef HUF_DEBUG
-__device__ unsigned long long g_hufdbg[16];
-extern "C" int press_hip_debug_huff(unsigned long long *dst)
-{
-	int rc = (int) hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_hufdbg), sizeof g_hufdbg);
-	unsigned long long z[16] = { 0 };
-	(void) hipMemcpyToSymbol(HIP_SYMBOL(g_hufdbg), z, sizeof z);
-	return rc;
-}
-// per-workgroup accumulation in registers, one atomicAdd per counter when the workgroup exits
-#define HSTAMP(i) do { const unsigned long long now_ = clock64(); acc_[i] += now_ - stamp_; stamp_ = now_; } while (0)
-#define HCOUNT(i, v) do { acc_[i] += (unsigned long long) (v); } while (0)
-#else
-#define HSTAMP(i) do { } while (0)
-#define HCOUNT(i, v) do { } while (0)
-#endif
 
 __global__ __launch_bounds__(HUF_HT, 6) void k_huff_decode_tiles(DecodeArgs a) // 6 waves per SIMD = 3 workgroups per CU
 {

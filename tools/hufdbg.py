@@ -16,4 +16,5 @@ print("tiles", buf[8], "rounds/tile", buf[9] / tiles, "redecodes/tile", buf[11] 
 for i, nm in enumerate(names):
     print("%-20s %10.0f ticks/tile  %5.1f %%" % (nm, buf[i] / tiles, 100.0 * buf[i] / max(1, tot)))
 print("total ticks/tile", tot / tiles)
+print("look-back polls that had to be repeated: %.3f per tile" % (buf[14] / tiles))
 print("inside the rounds: detection %.0f ticks/tile, re-decode %.0f ticks/tile" % (buf[12] / tiles, buf[13] / tiles))
