@@ -427,10 +427,12 @@ class Blow5Reader:
             self._h = ctypes.c_void_p()
 
 
-def blow5_transcode(src, dst, record_method=1, signal_method=1, codec=None):
+def blow5_transcode(src, dst, record_method=1, signal_method=1, codec=None, passthrough=False):
     """BLOW5 -> BLOW5 with the signal fields re-coded: codec(list of int16 arrays) -> list of svb-zd
     streams (default: the device, press_batch_host("slow5_svb_zd")); signal_method 0 writes the raw
     samples.  Signals of the source are decoded on the device when it stores them as svb-zd.
+    passthrough: keep the signal fields as they are (source and target signal method must agree;
+    no GPU involved - only the record framing / record compression changes).
     Returns the number of reads written."""
     lib = load_library()
     lib.press_hip_blow5_last_error.restype = ctypes.c_char_p
@@ -461,13 +463,20 @@ def blow5_transcode(src, dst, record_method=1, signal_method=1, codec=None):
                 break
             recs = [arena[int(ro[k]):int(ro[k]) + int(rl[k])] for k in range(got.value)]
             fields = [r[int(sp[k]):int(sp[k]) + int(sl[k])].tobytes() for k, r in enumerate(recs)]
-            if rd.signal_method == 1:
+            if passthrough:
+                if rd.signal_method != signal_method:
+                    raise PressError("passthrough needs the same signal method on both sides")
+                out = fields
+                sigs = None
+            elif rd.signal_method == 1:
                 sigs = depress_batch_host("slow5_svb_zd", fields, [int(x) for x in ns[:got.value]])
                 if any(s is None for s in sigs):
                     raise PressError("a signal of %s does not decode" % src)
             else:
                 sigs = [np.frombuffer(f, dtype=np.int16) for f in fields]
-            if signal_method == 1:
+            if passthrough:
+                pass
+            elif signal_method == 1:
                 out = (codec or (lambda reads: press_batch_host("slow5_svb_zd", reads)))(sigs)
             else:
                 out = [np.ascontiguousarray(s, dtype=np.int16).tobytes() for s in sigs]

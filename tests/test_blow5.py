@@ -196,3 +196,18 @@ def test_gpu_transcode_is_read_by_the_reference(tmp_path, rec, sig):
     if sig == 1:
         assert [(i, s) for i, _, s in rd.next_batch()] == parse_blow5_py(BLOW5)
     rd.close()
+
+
+@pytest.mark.parametrize("rec", [0, 1])
+def test_reframe_without_gpu(tmp_path, rec):
+    """reader -> writer with the signal fields passed through (no GPU): the reference's slow5lib
+    reads the re-framed file, and our reader gets the same fields back"""
+    dst = str(tmp_path / "reframed.blow5")
+    assert press.blow5_transcode(BLOW5, dst, record_method=rec, signal_method=1, passthrough=True) == 3
+    rd = press.Blow5Reader(dst)
+    assert (rd.record_method, rd.signal_method) == (rec, 1)
+    assert [(i, s) for i, _, s in rd.next_batch()] == parse_blow5_py(BLOW5)
+    rd.close()
+    got = _ref_dump(dst, tmp_path)
+    gold = golden_reads()
+    assert set(got) == set(gold) and all(np.array_equal(got[k], gold[k]) for k in gold)
