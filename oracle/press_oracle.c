@@ -693,6 +693,7 @@ uint64_t po_bound(int method, uint32_t n)
 	case PM_VBE21_ZD: case PM_VBBE21_ZD: case PM_VBSBE21_ZD: case PM_VBSSE21_ZD:
 	case PM_SHUFF_VBE21_ZD: case PM_SHUFF_VBBE21_ZD: case PM_SHUFF_VBSBE21_ZD:
 	case PM_SHUFF_VBSSE21_ZD: return vb_zd_bound(n);                           /* press.c:3411,4409 */
+	case PM_RC_VBE21_ZD:      return vb_zd_bound(n);                           /* press.c:5422 */
 	case PM_HASGAM_ZDQ:       return svb32_bound((uint32_t) vb_zd_bound(n));   /* press.c:8461 */
 	case PM_ZSTD_HASGAM_ZDQ:  return zstd_bound_(svb32_bound((uint32_t) vb_zd_bound(n)));
 	/* slow5_press.c:1037: __slow5_streamvbyte_max_compressedbytes(n) (streamvbyte.h:31, no padding) + the u32 count */
@@ -703,10 +704,159 @@ uint64_t po_bound(int method, uint32_t n)
 
 /* ------------------------------------------------------------------ method bodies */
 
+/* ------------------------------------------------------------------ order-0 binary range coder (8f-1)
+ *
+ * What the reference calls rcsenc / rcsdec (Turbo-Range-Coder, "simple predictor", press.c:5456,
+ * 5489): a 64-bit range coder that emits 32-bit little-endian words, 15-bit probabilities of a
+ * ONE bit kept in 255 contexts (the bits of the byte already coded, MSB first), all starting at
+ * one half.  Restated from its behaviour (the compiled reference is the check, tests/
+ * test_oracle_golden.py):
+ *   bit b with probability p:  x = (range >> 15) * p;  b ? range = x : (range -= x, low += x);
+ *                              a carry out of `low` increments the words already written;
+ *   update:  b ? p += ceil((32768 - p) / 32) - 1  :  p -= p >> 5;
+ *   renormalisation (range < 2^32: emit the top word of low, shift both by 32) is looked at only
+ *   before the bits 7, 5, 3 and 1 of a byte - two bits cost at most 30 bits of range;
+ *   end: renormalise, then low += 2^32 and one word if range > 2^33, else low += 1 and two words;
+ *   give-up rule (rcutil_.h:161): as soon as the output reaches n*255/256 - 8 bytes the input is
+ *   stored raw instead - for which the reference has no decoder, so such streams (in practice:
+ *   reads of fewer than ~40 samples) are outside its lossless domain.
+ */
+struct rc_enc {
+	uint64_t low, range;
+	uint8_t *out;
+	uint64_t pos; /* bytes written */
+};
+
+static void rc_put32(struct rc_enc *c, uint32_t w)
+{
+	c->out[c->pos++] = (uint8_t) w;
+	c->out[c->pos++] = (uint8_t) (w >> 8);
+	c->out[c->pos++] = (uint8_t) (w >> 16);
+	c->out[c->pos++] = (uint8_t) (w >> 24);
+}
+
+static void rc_carry(struct rc_enc *c)
+{
+	uint64_t q = c->pos;
+	while (q >= 4) { /* the reference would walk past the start of its buffer; it never has to */
+		uint32_t w;
+		q -= 4;
+		w = get_u32(c->out + q) + 1;
+		put_u32(c->out + q, w);
+		if (w)
+			break;
+	}
+}
+
+static void rc_norm(struct rc_enc *c)
+{
+	if (c->range < ((uint64_t) 1 << 32)) {
+		c->range <<= 32;
+		rc_put32(c, (uint32_t) (c->low >> 32));
+		c->low <<= 32;
+	}
+}
+
+static void rc_bit(struct rc_enc *c, uint16_t *p, unsigned bit)
+{
+	const uint64_t x = (c->range >> 15) * *p, before = c->low;
+	if (bit) {
+		c->range = x;
+		*p = (uint16_t) (*p + (32768u - *p + 31u) / 32u - 1u);
+	} else {
+		c->range -= x;
+		c->low += x;
+		*p = (uint16_t) (*p - (*p >> 5));
+	}
+	if (before > c->low)
+		rc_carry(c);
+}
+
+/* out must have room for n + n/2 + 64 bytes; returns the stream length */
+uint64_t po_rcs_encode(const uint8_t *in, uint64_t n, uint8_t *out)
+{
+	struct rc_enc c = { 0, ~(uint64_t) 0, out, 0 };
+	uint16_t mb[256];
+	uint64_t i;
+	const int64_t giveup = (int64_t) (n * 255 / 256) - 8;
+	int k;
+	for (k = 0; k < 256; k++)
+		mb[k] = 1u << 14;
+	for (i = 0; i < n; i++) {
+		const unsigned x = 0x100u | in[i];
+		for (k = 7; k >= 0; k--) {
+			if (k & 1)
+				rc_norm(&c);
+			rc_bit(&c, &mb[x >> (k + 1)], (x >> k) & 1u);
+		}
+		if ((int64_t) c.pos >= giveup) {
+			memcpy(out, in, n);
+			return n;
+		}
+	}
+	rc_norm(&c);
+	{
+		const uint64_t before = c.low;
+		if (c.range > ((uint64_t) 1 << 33)) {
+			c.low += (uint64_t) 1 << 32;
+			if (before > c.low)
+				rc_carry(&c);
+			rc_put32(&c, (uint32_t) (c.low >> 32));
+		} else {
+			c.low += 1;
+			if (before > c.low)
+				rc_carry(&c);
+			rc_put32(&c, (uint32_t) (c.low >> 32));
+			rc_put32(&c, (uint32_t) c.low);
+		}
+	}
+	return c.pos;
+}
+
+/* decodes n bytes; reads past `len` as zeros (the reference reads whatever follows) */
+void po_rcs_decode(const uint8_t *in, uint64_t len, uint64_t n, uint8_t *out)
+{
+	uint64_t range = ~(uint64_t) 0, code = 0, pos = 0, i;
+	uint16_t mb[256];
+	int k;
+#define RC_GET32() (pos + 4 <= len ? get_u32(in + pos) : 0u); pos += 4
+	for (k = 0; k < 256; k++)
+		mb[k] = 1u << 14;
+	for (k = 0; k < 2; k++) {
+		const uint32_t w = RC_GET32();
+		code = (code << 32) | w;
+	}
+	for (i = 0; i < n; i++) {
+		unsigned x = 1;
+		for (k = 7; k >= 0; k--) {
+			uint16_t *p = &mb[x];
+			uint64_t t;
+			if ((k & 1) && range < ((uint64_t) 1 << 32)) {
+				const uint32_t w = RC_GET32();
+				range <<= 32;
+				code = (code << 32) | w;
+			}
+			t = (range >> 15) * *p;
+			if (code < t) {
+				range = t;
+				*p = (uint16_t) (*p + (32768u - *p + 31u) / 32u - 1u);
+				x = 2 * x + 1;
+			} else {
+				range -= t;
+				code -= t;
+				*p = (uint16_t) (*p - (*p >> 5));
+				x = 2 * x;
+			}
+		}
+		out[i] = (uint8_t) x;
+	}
+#undef RC_GET32
+}
+
 static enum exfmt exfmt_of(int method)
 {
 	switch (method) {
-	case PM_VBE21_ZD: case PM_SHUFF_VBE21_ZD:     return EX_VBE21;
+	case PM_VBE21_ZD: case PM_SHUFF_VBE21_ZD: case PM_RC_VBE21_ZD: return EX_VBE21;
 	case PM_VBBE21_ZD: case PM_SHUFF_VBBE21_ZD:   return EX_VBBE21;
 	case PM_VBSBE21_ZD: case PM_SHUFF_VBSBE21_ZD: return EX_VBSBE21;
 	case PM_VBSSE21_ZD: case PM_SHUFF_VBSSE21_ZD: return EX_VBSSE21;
@@ -751,7 +901,17 @@ static int vb_family_press(int method, const int16_t *in, uint32_t n, uint8_t *o
 	put_u16(out, z[0]);
 	memcpy(out + 2, sec, seclen);
 	o = 2 + seclen;
-	if (is_shuff(method)) {
+	if (method == PM_RC_VBE21_ZD) { /* press.c:5427: the one-byte values through rcsenc */
+		uint8_t *tmp = malloc((size_t) nlow + nlow / 2 + 64);
+		const uint64_t rl = po_rcs_encode(low, nlow, tmp);
+		if (o + rl > cap) {
+			free(tmp);
+			goto done;
+		}
+		memcpy(out + o, tmp, rl);
+		free(tmp);
+		o += rl;
+	} else if (is_shuff(method)) {
 		uint64_t hl = cap - o;
 		if (po_shuff_encode(low, (uint32_t) nlow, out + o, &hl))
 			goto done;
@@ -791,7 +951,14 @@ static int vb_family_depress(int method, const uint8_t *in, uint64_t nbytes, uin
 	}
 	z = malloc(((size_t) n + 1) * sizeof *z);
 	z[0] = get_u16(in);
-	if (is_shuff(method)) {
+	if (method == PM_RC_VBE21_ZD) { /* press.c:5465: n is the exact sample count, so the byte count is known */
+		if ((uint64_t) e.n + 1 > n)
+			goto done;
+		nlow = (uint64_t) n - 1 - e.n;
+		low = malloc((size_t) nlow + 1);
+		po_rcs_decode(in + 2 + seclen, nbytes - 2 - seclen, nlow, low);
+		lowp = low;
+	} else if (is_shuff(method)) {
 		uint32_t got = 0;
 		low = malloc((size_t) n + 1);
 		ret = po_shuff_decode(in + 2 + seclen, nbytes - 2 - seclen, low, n, &got);
@@ -1001,6 +1168,7 @@ int po_press(int method, const int16_t *in, uint32_t n, uint8_t *out, uint64_t *
 	case PM_VBE21_ZD: case PM_VBBE21_ZD: case PM_VBSBE21_ZD: case PM_VBSSE21_ZD:
 	case PM_SHUFF_VBE21_ZD: case PM_SHUFF_VBBE21_ZD: case PM_SHUFF_VBSBE21_ZD:
 	case PM_SHUFF_VBSSE21_ZD:
+	case PM_RC_VBE21_ZD:
 		return vb_family_press(method, in, n, out, nout);
 	case PM_SLOW5_SVB_ZD: {
 		/* slow5_press.c:1054 ptr_compress_svb_zd: samples widened to int32, zig-zag delta in 32 bits
@@ -1055,6 +1223,7 @@ int po_depress(int method, const uint8_t *in, uint64_t nbytes, uint32_t n,
 	case PM_VBE21_ZD: case PM_VBBE21_ZD: case PM_VBSBE21_ZD: case PM_VBSSE21_ZD:
 	case PM_SHUFF_VBE21_ZD: case PM_SHUFF_VBBE21_ZD: case PM_SHUFF_VBSBE21_ZD:
 	case PM_SHUFF_VBSSE21_ZD:
+	case PM_RC_VBE21_ZD:
 		return vb_family_depress(method, in, nbytes, n, out, nout);
 	case PM_SLOW5_SVB_ZD: {
 		/* slow5_press.c:1110 ptr_depress_svb_zd -> :1085 ptr_depress_svb: the count comes from

@@ -22,6 +22,7 @@ METHODS = {
     "shuffman_vbe21_zd": 9, "shuffman_vbbe21_zd": 10, "shuffman_vbsbe21_zd": 11,
     "shuffman_vbsse21_zd": 12, "hasgam_vbsse21_zdq": 13, "zstd_hasgam_vbsse21_zdq": 14,
     "slow5_svb_zd": 15,  # BLOW5's signal codec (slow5lib svb-zd), SURVEY 8f-2
+    "rc_vbe21_zd": 16,   # vbe21 + TurboRC order-0 range coder, SURVEY 8f-1
 }
 DETERMINISTIC = [m for m in METHODS if not m.startswith("zstd_")]
 
