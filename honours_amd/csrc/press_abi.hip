@@ -161,12 +161,14 @@ bool is_zstd(int m)
 {
 	return m == PRESS_HIP_ZSTD_SVB_ZD || m == PRESS_HIP_ZSTD_SVB12_ZD || m == PRESS_HIP_ZSTD_HASGAM_ZDQ;
 }
-bool is_ex(int m) { return m >= PRESS_HIP_VBE21_ZD && m <= PRESS_HIP_HASGAM_ZDQ; }
+bool is_rc(int m) { return m == PRESS_HIP_RC_VBE21_ZD; }
+bool is_ex(int m) { return (m >= PRESS_HIP_VBE21_ZD && m <= PRESS_HIP_HASGAM_ZDQ) || is_rc(m); }
+int entropy_of(int m) { return is_shuff(m) ? 1 : is_rc(m) ? 2 : 0; }
 
 int exfmt_of(int m)
 {
 	switch (m) {
-	case PRESS_HIP_VBE21_ZD: case PRESS_HIP_SHUFF_VBE21_ZD:     return EXF_VBE21;
+	case PRESS_HIP_VBE21_ZD: case PRESS_HIP_SHUFF_VBE21_ZD: case PRESS_HIP_RC_VBE21_ZD: return EXF_VBE21;
 	case PRESS_HIP_VBBE21_ZD: case PRESS_HIP_SHUFF_VBBE21_ZD:   return EXF_VBBE21;
 	case PRESS_HIP_VBSBE21_ZD: case PRESS_HIP_SHUFF_VBSBE21_ZD: return EXF_VBSBE21;
 	case PRESS_HIP_VBSSE21_ZD: case PRESS_HIP_SHUFF_VBSSE21_ZD: return EXF_VBSSE21;
@@ -329,6 +331,8 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 			if (g.cbits.reserve(mc * sizeof(ChunkBits)))
 				return PRESS_HIP_EHIP;
 		}
+		if (is_rc(method) && g.low.reserve(total_samples + 64)) // the one-byte values between the two stages
+			return PRESS_HIP_EHIP;
 		if (decode && is_shuff(method)) {
 			const size_t mt = max_htiles_of(total_samples, nreads);
 			if (g.low.reserve(total_samples + 64) || g.htiles.reserve(mt * sizeof(HufTile)) ||
@@ -523,8 +527,8 @@ static int launch_press(int method, const BatchArgs &a, hipStream_t s)
 	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_encode(a, true, true, s) : launch_svb_encode_chunked(a, true, true, s); break;
 	case PRESS_HIP_SLOW5_SVB_ZD: launch_svb_encode_chunked(a, true, true, s, true); break;
 	default:
-		v1 ? launch_ex_encode(a, exfmt_of(method), is_shuff(method), s)
-		   : launch_ex_encode_chunked(a, exfmt_of(method), is_shuff(method), s);
+		(v1 && !is_rc(method)) ? launch_ex_encode(a, exfmt_of(method), is_shuff(method), s)
+				       : launch_ex_encode_chunked(a, exfmt_of(method), entropy_of(method), s);
 	}
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess)
@@ -541,8 +545,8 @@ static int launch_depress(int method, const DecodeArgs &a, hipStream_t s)
 	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_decode(a, true, true, s) : launch_svb_decode_chunked(a, true, true, s); break;
 	case PRESS_HIP_SLOW5_SVB_ZD: launch_svb_decode_chunked(a, true, true, s, true); break;
 	default:
-		v1 ? launch_ex_decode(a, exfmt_of(method), is_shuff(method), s)
-		   : launch_ex_decode_chunked(a, exfmt_of(method), is_shuff(method), s);
+		(v1 && !is_rc(method)) ? launch_ex_decode(a, exfmt_of(method), is_shuff(method), s)
+				       : launch_ex_decode_chunked(a, exfmt_of(method), entropy_of(method), s);
 	}
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess)
@@ -589,6 +593,8 @@ extern "C" int press_hip_press_batch(int method, const int16_t *sig, const uint6
 	a.max_chunks = max_chunks_of(total_samples, nreads);
 	if (is_shuff(method))
 		a.cbits = (ChunkBits *) g.cbits.p;
+	if (is_rc(method))
+		a.low_tmp = (uint8_t *) g.low.p;
 	a.first_chunk = (uint32_t *) g.first_chunk.p;
 
 	if (device_resident) {
@@ -1138,6 +1144,17 @@ VB_FAMILY(vbe21, PRESS_HIP_VBE21_ZD)
 VB_FAMILY(vbbe21, PRESS_HIP_VBBE21_ZD)
 VB_FAMILY(vbsbe21, PRESS_HIP_VBSBE21_ZD)
 VB_FAMILY(vbsse21, PRESS_HIP_VBSSE21_ZD)
+
+// rc_vbe21_zd (press.h:712-716): same shape; *nout of depress must be the exact sample count (press.c:5464)
+uint64_t rc_vbe21_zd_bound_16(uint32_t nin) { return press_hip_bound(PRESS_HIP_RC_VBE21_ZD, nin); }
+void rc_vbe21_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout)
+{
+	void_press(PRESS_HIP_RC_VBE21_ZD, in, nin, out, nout);
+}
+void rc_vbe21_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout)
+{
+	void_depress(PRESS_HIP_RC_VBE21_ZD, in, nin, out, nout);
+}
 
 #define SHUFF_FAMILY(name, id)                                                                           \
 	uint64_t shuffman_##name##_zd_bound_16(uint32_t nin) { return bound_vbzd(nin); }                 \

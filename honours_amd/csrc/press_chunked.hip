@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(CWG) void k_low_encode_chunked(BatchArgs a)
 	const int q = (int) uni(m->q);
 	const int16_t *in = a.sig + d.sig_off;
 	// one-byte value of sample i (i >= 1) goes to stream[(i - 1) - #exceptions before i]
-	uint8_t *stream = a.out + d.out_base + uni(m->hdr) + uni(m->seclen);
+	uint8_t *stream = a.low_tmp ? a.low_tmp + d.sig_off : a.out + d.out_base + uni(m->hdr) + uni(m->seclen);
 	const uint32_t e0 = uni(dp->ecnt[0]), e1 = uni(dp->ecnt[1]), e2 = uni(dp->ecnt[2]);
 	uint64_t eb = uni64(dp->ebefore) + (w > 0 ? e0 : 0u) + (w > 1 ? e1 : 0u) + (w > 2 ? e2 : 0u);
 
@@ -1963,8 +1963,9 @@ static void run_decode(const DecodeArgs &a, hipStream_t s)
 }
 
 // exception-split encode: chunked scan, section per read, chunked pass B
-void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
+void launch_ex_encode_chunked(const BatchArgs &a, int fmt, int ent, hipStream_t s)
 {
+	const bool huff = ent == 1;
 	if (!a.nreads || !a.max_chunks)
 		return;
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
@@ -1983,7 +1984,14 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_
 	}
 	hipLaunchKernelGGL(k_ex_prefix, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a, fmt == EXF_EXZD ? 1 : 0);
 	hipLaunchKernelGGL(k_ex_list, dim3(a.max_chunks), dim3(CWG), 0, s, a);
-	launch_ex_section(a, fmt, huff, s);
+	launch_ex_section(a, fmt, ent, s);
+	if (ent == 2) { // range coder: the one-byte values go to a temporary, one lane per read codes them
+		hipLaunchKernelGGL(k_low_encode_chunked, dim3(a.max_chunks), dim3(CWG), 0, s, a);
+		ktime_begin(0, s);
+		launch_rcs_encode(a, s);
+		ktime_end(0, s);
+		return;
+	}
 	ktime_begin(0, s);
 	if (huff)
 		hipLaunchKernelGGL(k_huff_encode_chunked, dim3(a.max_chunks), dim3(CWG), 0, s, a);
@@ -1993,11 +2001,12 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_
 }
 
 // exception-split decode: parse + (Huffman) from press_kernels.hip, then the chunked merge
-void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, bool huff, hipStream_t s)
+void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, int ent, hipStream_t s)
 {
+	const bool huff = ent != 0; // the one-byte stream comes from a.low (Huffman or range decoder)
 	if (!a.nreads || !a.max_chunks)
 		return;
-	launch_ex_parse_huff(a, fmt, huff, s);
+	launch_ex_parse_huff(a, fmt, ent, s);
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL(k_chunk_prep_meta, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off, a.in_off,
 			   a.meta, a.nreads, a.chunks, a.gran, a.ctl, a.max_chunks, a.out_n);

@@ -105,6 +105,7 @@ struct BatchArgs {
 	ChunkCtl *ctl;            // zeroed per launch
 	uint32_t max_chunks;      // >= sum over reads of ceil(n / CHUNK)
 	ChunkBits *cbits;         // [max_chunks] Huffman code-bit counts (NULL for the other methods)
+	uint8_t *low_tmp;         // range-coder methods: the one-byte values of read r at low_tmp[off[r]..] (else NULL)
 	uint32_t *first_chunk;    // [nreads] id of the first chunk of read r (exception-split encode)
 };
 
@@ -152,12 +153,14 @@ void ktime_end(int which, hipStream_t s);
 void launch_svb_encode(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s);      // v1: one workgroup per read
 void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s, bool slow5 = false); // v2: chunks + look-back
 void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s, bool slow5 = false);
-void launch_ex_encode_chunked(const BatchArgs &a, int fmt, bool huff, hipStream_t s);
-void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, bool huff, hipStream_t s);
-void launch_ex_parse_huff(const DecodeArgs &a, int fmt, bool huff, hipStream_t s); // press_kernels.hip
+void launch_ex_encode_chunked(const BatchArgs &a, int fmt, int ent, hipStream_t s); // ent: 0 plain, 1 Huffman, 2 range coder
+void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, int ent, hipStream_t s);
+void launch_ex_parse_huff(const DecodeArgs &a, int fmt, int ent, hipStream_t s); // press_kernels.hip
 void launch_huff_decode(const DecodeArgs &a, hipStream_t s);                       // press_huffman.hip
 // pieces of the v1 pipeline reused by the chunked one (press_kernels.hip)
-void launch_ex_section(const BatchArgs &a, int fmt, bool huff, hipStream_t s);
+void launch_ex_section(const BatchArgs &a, int fmt, int ent, hipStream_t s);
+void launch_rcs_encode(const BatchArgs &a, hipStream_t s);  // press_rc.hip
+void launch_rcs_decode(const DecodeArgs &a, hipStream_t s);
 void launch_svb_decode(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s);
 // exception-split encode: scan (+ qts redo for ex-zd) -> section -> one-byte / Huffman stream
 void launch_ex_encode(const BatchArgs &a, int fmt, bool huff, hipStream_t s);

@@ -609,11 +609,12 @@ __global__ __launch_bounds__(64) void k_ex_section(BatchArgs a, int fmt, int huf
 	}
 	const uint64_t nlow = (uint64_t) (n - 1) - nex;
 	// one-byte stream: raw, or at least the 4-byte count of the Huffman stream
-	const uint64_t need = hdr + seclen + (huff ? 4 : nlow);
+	// (huff: 0 plain, 1 / 2 static Huffman (v1 / chunked pass B), 3 range coder: its stream is sized by k_rcs_encode)
+	const uint64_t need = hdr + seclen + (huff == 3 ? 0 : huff ? 4 : nlow);
 	if (need > cap)
 		return;
 	// press.c:4520,4636,4752: the b/sb/ss Huffman variants keep the section length in a uint16_t
-	if (huff && fmt != EXF_VBE21 && seclen > 65535)
+	if (huff && huff != 3 && fmt != EXF_VBE21 && seclen > 65535)
 		return;
 	// ex_zd.c:411: the reference works in a 2n+1024-byte buffer
 	if (fmt == EXF_EXZD && need > 2ull * n + 1024)
@@ -987,7 +988,10 @@ __global__ __launch_bounds__(64) void k_ex_parse(DecodeArgs a, int fmt, int huff
 	m->nex = nex;
 	m->seclen = (uint32_t) seclen;
 	uint64_t nlow;
-	if (huff) {
+	if (huff == 3) {
+		// press.c:5465: the caller passes the exact sample count, the rest are one-byte values
+		nlow = (uint64_t) cap - 1 - nex;
+	} else if (huff) {
 		// huffman.c:1236 + :704: at least one payload byte behind the 4-byte count
 		const uint64_t hl = len - hdr - seclen;
 		if (hl <= 4)
@@ -1164,9 +1168,9 @@ void launch_svb_decode(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s
 	ktime_end(1, s);
 }
 
-void launch_ex_section(const BatchArgs &a, int fmt, bool huff, hipStream_t s)
+void launch_ex_section(const BatchArgs &a, int fmt, int ent, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_ex_section, dim3(a.nreads), dim3(64), 0, s, a, fmt, huff ? 2 : 0);
+	hipLaunchKernelGGL(k_ex_section, dim3(a.nreads), dim3(64), 0, s, a, fmt, ent == 1 ? 2 : ent == 2 ? 3 : 0);
 	if (fmt == EXF_VBE21)
 		hipLaunchKernelGGL(k_ex_fill_vbe21, dim3(a.nreads), dim3(64), 0, s, a);
 }
@@ -1193,14 +1197,17 @@ void launch_ex_encode(const BatchArgs &a0, int fmt, bool huff, hipStream_t s)
 
 // k_ex_parse and, for the Huffman variants, the stream decode into a.low (timed as the
 // dominant kernel of those methods)
-void launch_ex_parse_huff(const DecodeArgs &a, int fmt, bool huff, hipStream_t s)
+void launch_ex_parse_huff(const DecodeArgs &a, int fmt, int ent, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_ex_parse, dim3(a.nreads), dim3(64), 0, s, a, fmt, huff ? 1 : 0);
+	hipLaunchKernelGGL(k_ex_parse, dim3(a.nreads), dim3(64), 0, s, a, fmt, ent == 2 ? 3 : ent);
 	if (fmt == EXF_VBE21)
 		hipLaunchKernelGGL(k_ex_parse_fill_vbe21, dim3(a.nreads), dim3(64), 0, s, a);
-	if (huff) {
+	if (ent) {
 		ktime_begin(1, s);
-		launch_huff_decode(a, s);
+		if (ent == 2)
+			launch_rcs_decode(a, s);
+		else
+			launch_huff_decode(a, s);
 		ktime_end(1, s);
 	}
 }

@@ -1,0 +1,227 @@
+// press_rc.hip - the order-0 adaptive binary range coder of rc_vbe21_zd:
+// TurboRC's rcsenc / rcsdec as the reference calls them (press.c:5456, 5489) on the one-byte
+// values of the vbe21 exception split.
+//
+// The format leaves a GPU nothing to parallelise inside a read: the 255 adaptive probabilities
+// and the 64-bit interval run through the whole stream, bit by bit (~1 M dependent steps for a
+// mean NA12878 read), and nothing marks a position where a second coder could start.  So this
+// is ONE READ PER LANE: a wave codes 64 reads side by side, its probability tables in LDS
+// (256 x 64 dwords, the lane is the bank - conflict free whatever the contexts), and a batch
+// lasts as long as its longest read.  It is here for coverage of the reference's entropy
+// stages, bit-exact like everything else; its throughput is what the format allows
+// (DESIGN.md section 6).
+//
+// Coder (restated from its behaviour, pinned against the compiled reference by
+// oracle/press_oracle.c:po_rcs_encode and tests/test_oracle_golden.py):
+//   state   range = 2^64 - 1, low = 0; output in 32-bit little-endian words;
+//   bit b, probability p of a ONE (15 bits, context = bits of the byte coded so far):
+//           x = (range >> 15) * p;  b ? range = x : (range -= x, low += x); a carry out of low
+//           increments the words already written;  b ? p += ceil((32768-p)/32) - 1 : p -= p >> 5;
+//   renormalisation (range < 2^32: emit the top word of low, shift both by 32) only before
+//           bits 7, 5, 3, 1 of a byte;
+//   end     renormalise; range > 2^33 ? (low += 2^32, one word) : (low += 1, two words);
+//   give-up (rcutil_.h:161) once the output reaches n*255/256 - 8 bytes the input is stored raw.
+
+#include "press_internal.h"
+
+namespace ph {
+
+namespace {
+
+constexpr uint64_t RC_TOP = 1ull << 32;
+
+struct RcOut {
+	uint8_t *out;
+	uint64_t cap;  // bytes the stream may take
+	uint64_t pos;  // bytes written
+	bool failed;   // the slot is too small
+};
+
+__device__ __forceinline__ void rc_put32(RcOut &o, uint32_t w)
+{
+	if (o.pos + 4 > o.cap) {
+		o.failed = true;
+	} else {
+		__builtin_memcpy(o.out + o.pos, &w, 4);
+	}
+	o.pos += 4;
+}
+
+__device__ __forceinline__ void rc_carry(RcOut &o)
+{
+	uint64_t q = o.pos;
+	while (q >= 4 && !o.failed) {
+		q -= 4;
+		uint32_t w;
+		__builtin_memcpy(&w, o.out + q, 4);
+		w += 1;
+		__builtin_memcpy(o.out + q, &w, 4);
+		if (w)
+			break;
+	}
+}
+
+} // namespace
+
+// one read per lane; the one-byte values of read r are a.low_tmp[off[r] ..) (k_low_encode_chunked)
+__global__ __launch_bounds__(64) void k_rcs_encode(BatchArgs a)
+{
+	__shared__ uint32_t mb[256][64];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t r = blockIdx.x * 64 + lane;
+	for (int c = 0; c < 256; c++)
+		mb[c][lane] = 1u << 14;
+	bool alive = r < a.nreads;
+	const ReadMeta *m = a.meta + (alive ? r : 0);
+	if (alive && m->status)
+		alive = false; // out_len = FAILED was written by k_ex_section
+	const uint64_t n = alive ? m->nlow : 0;
+	const uint32_t head = alive ? m->hdr + m->seclen : 0;
+	const uint8_t *in = a.low_tmp + (alive ? a.off[r] : 0);
+	RcOut o;
+	o.out = a.out + (alive ? a.out_off[r] + head : 0);
+	o.cap = alive ? a.out_off[r + 1] - a.out_off[r] - head : 0;
+	o.pos = 0;
+	o.failed = false;
+	uint64_t low = 0, range = ~0ull;
+	const long long giveup = (long long) (n * 255 / 256) - 8;
+	bool raw = false;
+	for (uint64_t i = 0;; i++) {
+		const bool act = alive && !raw && i < n;
+		if (!__any(act))
+			break;
+		if (act) {
+			const uint32_t x = 0x100u | in[i];
+#pragma unroll
+			for (int k = 7; k >= 0; k--) {
+				if ((k & 1) && range < RC_TOP) {
+					range <<= 32;
+					rc_put32(o, (uint32_t) (low >> 32));
+					low <<= 32;
+				}
+				uint32_t &pr = mb[x >> (k + 1)][lane];
+				const uint32_t p = pr;
+				const uint64_t t = (range >> 15) * p, before = low;
+				if ((x >> k) & 1u) {
+					range = t;
+					pr = p + (32768u - p + 31u) / 32u - 1u;
+				} else {
+					range -= t;
+					low += t;
+					pr = p - (p >> 5);
+				}
+				if (before > low)
+					rc_carry(o);
+			}
+			if ((long long) o.pos >= giveup)
+				raw = true; // rcutil_.h:161: stored instead
+		}
+	}
+	if (alive) {
+		if (raw) {
+			o.failed = n > o.cap;
+			if (!o.failed)
+				for (uint64_t i = 0; i < n; i++)
+					o.out[i] = in[i];
+			o.pos = n;
+		} else {
+			if (range < RC_TOP) {
+				range <<= 32;
+				rc_put32(o, (uint32_t) (low >> 32));
+				low <<= 32;
+			}
+			const uint64_t before = low;
+			if (range > (1ull << 33)) {
+				low += 1ull << 32;
+				if (before > low)
+					rc_carry(o);
+				rc_put32(o, (uint32_t) (low >> 32));
+			} else {
+				low += 1;
+				if (before > low)
+					rc_carry(o);
+				rc_put32(o, (uint32_t) (low >> 32));
+				rc_put32(o, (uint32_t) low);
+			}
+		}
+		a.out_len[r] = o.failed ? ~0ull : (uint64_t) head + o.pos;
+	}
+}
+
+// one read per lane: the rc stream behind the exception section -> a.low[off[r] ..)
+__global__ __launch_bounds__(64) void k_rcs_decode(DecodeArgs a)
+{
+	__shared__ uint32_t mb[256][64];
+	const uint32_t lane = threadIdx.x;
+	const uint32_t r = blockIdx.x * 64 + lane;
+	for (int c = 0; c < 256; c++)
+		mb[c][lane] = 1u << 14;
+	bool alive = r < a.nreads;
+	const ReadMeta *m = a.meta + (alive ? r : 0);
+	if (alive && m->status)
+		alive = false;
+	const uint64_t n = alive ? m->nlow : 0;
+	const uint32_t head = alive ? m->hdr + m->seclen : 0;
+	const uint8_t *in = a.in + (alive ? a.in_off[r] + head : 0);
+	const uint64_t len = alive ? a.in_len[r] - head : 0;
+	uint8_t *out = a.low + (alive ? a.off[r] : 0);
+	uint64_t pos = 0, range = ~0ull, code = 0;
+	// bytes past the end of the stream read as zeros (the reference reads whatever follows)
+	auto get32 = [&]() -> uint32_t {
+		uint32_t w = 0;
+		if (pos + 4 <= len) {
+			__builtin_memcpy(&w, in + pos, 4);
+		} else {
+			for (int b = 0; b < 4; b++)
+				if (pos + b < len)
+					w |= (uint32_t) in[pos + b] << (8 * b);
+		}
+		pos += 4;
+		return w;
+	};
+	if (alive) {
+		code = get32();
+		code = (code << 32) | get32();
+	}
+	for (uint64_t i = 0;; i++) {
+		const bool act = alive && i < n;
+		if (!__any(act))
+			break;
+		if (act) {
+			uint32_t x = 1;
+#pragma unroll
+			for (int k = 7; k >= 0; k--) {
+				if ((k & 1) && range < RC_TOP) {
+					range <<= 32;
+					code = (code << 32) | get32();
+				}
+				uint32_t &pr = mb[x][lane];
+				const uint32_t p = pr;
+				const uint64_t t = (range >> 15) * p;
+				if (code < t) {
+					range = t;
+					pr = p + (32768u - p + 31u) / 32u - 1u;
+					x = 2 * x + 1;
+				} else {
+					range -= t;
+					code -= t;
+					pr = p - (p >> 5);
+					x = 2 * x;
+				}
+			}
+			out[i] = (uint8_t) x;
+		}
+	}
+}
+
+void launch_rcs_encode(const BatchArgs &a, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_rcs_encode, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a);
+}
+
+void launch_rcs_decode(const DecodeArgs &a, hipStream_t s)
+{
+	hipLaunchKernelGGL(k_rcs_decode, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a);
+}
+
+} // namespace ph

@@ -131,6 +131,12 @@ uint64_t shuffman_vbsse21_zd_bound_16(uint32_t nin);
 int shuffman_vbsse21_zd_press_16(SymbolEncoder *se, const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
 int shuffman_vbsse21_zd_depress_16(huffman_node *root, uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
 
+/* ---- vbe21 + order-0 adaptive range coder (TurboRC rcsenc / rcsdec): press.h:712-716 (press.c:5422-5500).
+ * SURVEY 8f-1.  depress: *nout in = the exact sample count (press.c:5464). ---- */
+uint64_t rc_vbe21_zd_bound_16(uint32_t nin);
+void rc_vbe21_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+void rc_vbe21_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+
 /* ---- ex-zd v0: press.h:960-964 (press.c:8461-8500 over ex_zd.c:403,495) ---- */
 uint64_t hasgam_vbsse21_zdq_bound_16(uint32_t nin);
 int hasgam_vbsse21_zdq_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
@@ -174,7 +180,8 @@ enum press_hip_method {
 	PRESS_HIP_HASGAM_ZDQ       = 13,
 	PRESS_HIP_ZSTD_HASGAM_ZDQ  = 14, /* per-read API only */
 	PRESS_HIP_SLOW5_SVB_ZD     = 15, /* BLOW5's signal codec (section 3) */
-	PRESS_HIP_NMETHODS         = 16
+	PRESS_HIP_RC_VBE21_ZD      = 16, /* vbe21 + order-0 range coder: one read per lane (serial format) */
+	PRESS_HIP_NMETHODS         = 17
 };
 
 #define PRESS_HIP_OK        0

@@ -813,13 +813,23 @@ uint64_t po_rcs_encode(const uint8_t *in, uint64_t n, uint8_t *out)
 	return c.pos;
 }
 
-/* decodes n bytes; reads past `len` as zeros (the reference reads whatever follows) */
+static uint32_t rc_get32(const uint8_t *in, uint64_t len, uint64_t pos)
+{
+	uint32_t w = 0;
+	int b;
+	for (b = 0; b < 4; b++)
+		if (pos + (uint64_t) b < len)
+			w |= (uint32_t) in[pos + b] << (8 * b);
+	return w;
+}
+
+/* decodes n bytes; bytes past `len` read as zeros (the reference reads whatever follows) */
 void po_rcs_decode(const uint8_t *in, uint64_t len, uint64_t n, uint8_t *out)
 {
 	uint64_t range = ~(uint64_t) 0, code = 0, pos = 0, i;
 	uint16_t mb[256];
 	int k;
-#define RC_GET32() (pos + 4 <= len ? get_u32(in + pos) : 0u); pos += 4
+#define RC_GET32() rc_get32(in, len, pos); pos += 4
 	for (k = 0; k < 256; k++)
 		mb[k] = 1u << 14;
 	for (k = 0; k < 2; k++) {

@@ -54,6 +54,16 @@ def check_read(oracle, m, sig, want=None):
     if m in DET:
         assert got == want, (m, n, len(got), len(want))
     ret, back = press.depress(m, got, n)
+    if m == "rc_vbe21_zd":
+        # reference quirk (TurboRC rcutil_.h:161): once the coder's output reaches n*255/256 - 8 bytes it
+        # stores the bytes raw, and nothing tells rcsdec - such reads (a few dozen samples) are outside
+        # the reference's lossless domain; there the GPU must still do what the reference's decoder does
+        ro, oback = oracle.depress(m, want, n)
+        assert ro == 0 and ret == 0 and np.array_equal(back, oback), (m, n)
+        nex = int.from_bytes(want[2:6], "little")
+        if not (len(want) - 6 - 6 * nex == n - 1 - nex and n - 1 - nex > 0):  # not stored raw
+            assert np.array_equal(back, sig), (m, n)
+        return
     assert ret == 0 and back.size == n and np.array_equal(back, sig), (m, n)
     # and the oracle's stream decodes on the GPU (cross decode)
     ret, back = press.depress(m, want, n)

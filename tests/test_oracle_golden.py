@@ -162,6 +162,16 @@ def test_oracle_vs_reference_fuzz(oracle):
                 assert oracle.bound(m, n) == ref.bound(m, n)
                 if rr == 0:
                     dr, dd = oracle.depress(m, rc, n)
+                    if m == "rc_vbe21_zd":
+                        # TurboRC stores tiny / incompressible inputs raw (rcutil_.h:161) and its decoder
+                        # cannot tell: such streams are outside the reference's lossless domain (its own
+                        # decoder may even abort on them), so only the encoder is compared there
+                        nex = int.from_bytes(rc[2:6], "little")
+                        if len(rc) - 6 - 6 * nex == n - 1 - nex and n - 1 - nex > 0:
+                            continue
+                        er, ed = ref.depress(m, rc, n)
+                        assert dr == 0 and er == 0 and np.array_equal(dd, ed) and np.array_equal(dd, s), (m, n)
+                        continue
                     assert dr == 0 and np.array_equal(dd, s), (m, n)
     finally:
         os.dup2(saved, 2)
