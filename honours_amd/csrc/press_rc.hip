@@ -86,12 +86,30 @@ __global__ __launch_bounds__(64) void k_rcs_encode(BatchArgs a)
 	uint64_t low = 0, range = ~0ull;
 	const long long giveup = (long long) (n * 255 / 256) - 8;
 	bool raw = false;
+	// the input is fetched 16 bytes at a time, one fetch ahead: a load per byte would put an L1
+	// round trip (~0.1 us) on every byte's critical path.  (Reads past n stay inside the buffer's slack.)
+	uint4 cur = make_uint4(0, 0, 0, 0), nxt = make_uint4(0, 0, 0, 0);
+	if (alive && n)
+		__builtin_memcpy(&nxt, in, 16);
 	for (uint64_t i = 0;; i++) {
 		const bool act = alive && !raw && i < n;
 		if (!__any(act))
 			break;
+		if ((i & 15) == 0) { // i is wave uniform
+			cur = nxt;
+			if (alive && i + 16 < n)
+				__builtin_memcpy(&nxt, in + i + 16, 16);
+		}
 		if (act) {
-			const uint32_t x = 0x100u | in[i];
+			const uint32_t sel = (uint32_t) (i >> 2) & 3u;
+			const uint32_t dw = sel == 0 ? cur.x : sel == 1 ? cur.y : sel == 2 ? cur.z : cur.w;
+			const uint32_t x = 0x100u | ((dw >> (8 * ((uint32_t) i & 3u))) & 0xFFu);
+			// the eight contexts of a byte are known in advance (and distinct): fetch their
+			// probabilities together, so that the dependent chain is arithmetic only
+			uint32_t pp[8];
+#pragma unroll
+			for (int k = 7; k >= 0; k--)
+				pp[k] = mb[x >> (k + 1)][lane];
 #pragma unroll
 			for (int k = 7; k >= 0; k--) {
 				if ((k & 1) && range < RC_TOP) {
@@ -99,16 +117,15 @@ __global__ __launch_bounds__(64) void k_rcs_encode(BatchArgs a)
 					rc_put32(o, (uint32_t) (low >> 32));
 					low <<= 32;
 				}
-				uint32_t &pr = mb[x >> (k + 1)][lane];
-				const uint32_t p = pr;
+				const uint32_t p = pp[k];
 				const uint64_t t = (range >> 15) * p, before = low;
 				if ((x >> k) & 1u) {
 					range = t;
-					pr = p + (32768u - p + 31u) / 32u - 1u;
+					mb[x >> (k + 1)][lane] = p + (32768u - p + 31u) / 32u - 1u;
 				} else {
 					range -= t;
 					low += t;
-					pr = p - (p >> 5);
+					mb[x >> (k + 1)][lane] = p - (p >> 5);
 				}
 				if (before > low)
 					rc_carry(o);
@@ -179,9 +196,17 @@ __global__ __launch_bounds__(64) void k_rcs_decode(DecodeArgs a)
 		pos += 4;
 		return w;
 	};
+	// the next word is always in flight before it is needed
+	uint32_t wn = 0;
+	auto next32 = [&]() -> uint32_t {
+		const uint32_t w = wn;
+		wn = get32();
+		return w;
+	};
 	if (alive) {
-		code = get32();
-		code = (code << 32) | get32();
+		wn = get32();
+		code = next32();
+		code = (code << 32) | next32();
 	}
 	for (uint64_t i = 0;; i++) {
 		const bool act = alive && i < n;
@@ -189,24 +214,31 @@ __global__ __launch_bounds__(64) void k_rcs_decode(DecodeArgs a)
 			break;
 		if (act) {
 			uint32_t x = 1;
+			uint32_t p = mb[1][lane];
 #pragma unroll
 			for (int k = 7; k >= 0; k--) {
+				// both candidates for the next context while this bit is being decided
+				uint32_t c0 = 0, c1 = 0;
+				if (k) {
+					c0 = mb[2 * x][lane];
+					c1 = mb[2 * x + 1][lane];
+				}
 				if ((k & 1) && range < RC_TOP) {
 					range <<= 32;
-					code = (code << 32) | get32();
+					code = (code << 32) | next32();
 				}
-				uint32_t &pr = mb[x][lane];
-				const uint32_t p = pr;
 				const uint64_t t = (range >> 15) * p;
 				if (code < t) {
 					range = t;
-					pr = p + (32768u - p + 31u) / 32u - 1u;
+					mb[x][lane] = p + (32768u - p + 31u) / 32u - 1u;
 					x = 2 * x + 1;
+					p = c1;
 				} else {
 					range -= t;
 					code -= t;
-					pr = p - (p >> 5);
+					mb[x][lane] = p - (p >> 5);
 					x = 2 * x;
+					p = c0;
 				}
 			}
 			out[i] = (uint8_t) x;
