@@ -16,6 +16,7 @@
 
 #include "../../include/press_hip.h"
 #include "press_internal.h"
+#include "zs_table.h"
 
 using namespace ph;
 
@@ -81,9 +82,11 @@ struct Ctx {
 	bool use_user = false;
 	// scratch shared by both modes
 	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, hgran, cbits;
+	DevBuf ztmp, zoff, zoff4, zlen, zhist, ztab, zfirst, zblk, zsbits, zbpos, zbflag, zkcnt, zkbase, zrd, znb; // zstd frames
 	int use_v1 = -1; // PRESS_HIP_V1=1 selects the one-workgroup-per-read svb kernels (A/B)
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn;
+	uint64_t zs_total = 0; // total_samples of the batch in flight (sizes of the zstd scratch)
 	// static Huffman table currently on the device
 	bool have_table = false;
 	uint32_t tlen[256];
@@ -162,6 +165,7 @@ bool is_zstd(int m)
 	return m == PRESS_HIP_ZSTD_SVB_ZD || m == PRESS_HIP_ZSTD_SVB12_ZD || m == PRESS_HIP_ZSTD_HASGAM_ZDQ;
 }
 bool is_rc(int m) { return m == PRESS_HIP_RC_VBE21_ZD; }
+bool is_zs(int m) { return m == PRESS_HIP_ZSTD_SVB_ZD; } // zstd frames made on the device (batch API)
 bool is_ex(int m) { return (m >= PRESS_HIP_VBE21_ZD && m <= PRESS_HIP_HASGAM_ZDQ) || is_rc(m); }
 int entropy_of(int m) { return is_shuff(m) ? 1 : is_rc(m) ? 2 : 0; }
 
@@ -313,11 +317,47 @@ bool use_v1()
 	return g.use_v1 == 1;
 }
 
+uint32_t max_zblocks_of(uint64_t total_samples, uint32_t nreads)
+{
+	return (uint32_t) (total_samples * 2 / zs::BLOCK_LITS + nreads + 1);
+}
+
+void zs_bufs(ZsBufs &z, uint64_t total_samples, uint32_t nreads)
+{
+	z.ztmp = (uint8_t *) g.ztmp.p;
+	z.zoff = (uint64_t *) g.zoff.p;
+	z.zoff4 = (uint64_t *) g.zoff4.p;
+	z.zlen = (uint64_t *) g.zlen.p;
+	z.hist = (uint32_t *) g.zhist.p;
+	z.tab = g.ztab.p;
+	z.first_blk = (uint32_t *) g.zfirst.p;
+	z.blk_read = (uint32_t *) g.zblk.p;
+	z.sbits = (uint4 *) g.zsbits.p;
+	z.bpos = (uint32_t *) g.zbpos.p;
+	z.bflag = (uint8_t *) g.zbflag.p;
+	z.kcnt = (uint32_t *) g.zkcnt.p;
+	z.kbase = (uint32_t *) g.zkbase.p;
+	z.rd = (ZsRead *) g.zrd.p;
+	z.nblocks = (uint32_t *) g.znb.p;
+	z.max_blocks = max_zblocks_of(total_samples, nreads);
+}
+
 int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool decode)
 {
 	if (g.meta.reserve(((size_t) nreads + 1) * sizeof(ReadMeta)))
 		return PRESS_HIP_EHIP;
-	if (is_svb(method) || is_ex(method)) {
+	if (is_zs(method)) {
+		const size_t mc = max_chunks_of(total_samples, nreads), mb = max_zblocks_of(total_samples, nreads);
+		const size_t nr = (size_t) nreads + 1;
+		if (g.ztmp.reserve(total_samples * 9 / 4 + nr * 64 + 64) || g.zoff.reserve(nr * 8) || g.zoff4.reserve(nr * 8) ||
+		    g.zlen.reserve(nr * 8) || g.zhist.reserve(nr * 1024) || g.ztab.reserve(nr * sizeof(zs::Table)) ||
+		    g.zfirst.reserve(nr * 4) || g.zblk.reserve(mb * 4) || g.zsbits.reserve(mb * 16) || g.zbpos.reserve(mb * 4) ||
+		    g.zbflag.reserve(mb) || g.zkcnt.reserve(mc * 4) || g.zkbase.reserve(mc * 4) ||
+		    g.zrd.reserve(nr * sizeof(ZsRead)) || g.znb.reserve(64) ||
+		    g.ex_pos.reserve((total_samples + 64) * 4) || g.ex_val.reserve((total_samples + 64) * 4))
+			return PRESS_HIP_EHIP;
+	}
+	if (is_svb(method) || is_ex(method) || is_zs(method)) {
 		const size_t mc = max_chunks_of(total_samples, nreads);
 		if (g.chunks.reserve(mc * sizeof(ChunkDesc)) || g.gran.reserve(2 * mc * sizeof(uint64_t)) ||
 		    g.ctl.reserve(sizeof(ChunkCtl)) || g.first_chunk.reserve(((size_t) nreads + 1) * 4))
@@ -526,6 +566,12 @@ static int launch_press(int method, const BatchArgs &a, hipStream_t s)
 	case PRESS_HIP_SVB12_ZD: v1 ? launch_svb_encode(a, false, true, s) : launch_svb_encode_chunked(a, false, true, s); break;
 	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_encode(a, true, true, s) : launch_svb_encode_chunked(a, true, true, s); break;
 	case PRESS_HIP_SLOW5_SVB_ZD: launch_svb_encode_chunked(a, true, true, s, true); break;
+	case PRESS_HIP_ZSTD_SVB_ZD: {
+		ZsBufs z;
+		zs_bufs(z, g.zs_total, a.nreads);
+		launch_zstd_encode(a, z, s);
+		break;
+	}
 	default:
 		(v1 && !is_rc(method)) ? launch_ex_encode(a, exfmt_of(method), is_shuff(method), s)
 				       : launch_ex_encode_chunked(a, exfmt_of(method), entropy_of(method), s);
@@ -556,7 +602,7 @@ static int launch_depress(int method, const DecodeArgs &a, hipStream_t s)
 
 static int check_method(int method)
 {
-	if (method < 0 || method >= PRESS_HIP_NMETHODS || is_zstd(method))
+	if (method < 0 || method >= PRESS_HIP_NMETHODS || (is_zstd(method) && !is_zs(method)))
 		return fail(PRESS_HIP_EARG, "method %d is not available in the batch API", method);
 	if (is_shuff(method) && !g.have_table)
 		return fail(PRESS_HIP_ENOTABLE, "static-Huffman method without a table (press_hip_load_table_file)");
@@ -579,6 +625,7 @@ extern "C" int press_hip_press_batch(int method, const int16_t *sig, const uint6
 	hipStream_t s = g.stream();
 	if ((rc = reserve_scratch(method, total_samples, nreads, false)))
 		return rc;
+	g.zs_total = total_samples;
 
 	BatchArgs a;
 	memset(&a, 0, sizeof a);

@@ -1923,7 +1923,7 @@ static void run_encode(const BatchArgs &a, hipStream_t s)
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL((k_chunk_prep<false, KEY2>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off,
 			   a.nsamp, a.out_off, (const uint64_t *) nullptr, a.nreads, a.chunks, a.gran, a.ctl,
-			   a.max_chunks, a.out_len, (uint32_t *) nullptr, (uint32_t *) nullptr, (ReadMeta *) nullptr,
+			   a.max_chunks, a.out_len, (uint32_t *) nullptr, a.first_chunk, (ReadMeta *) nullptr,
 			   (const uint8_t *) nullptr, S5 ? 4u : 0u);
 	// persistent grid: as many workgroups as are resident (4 per CU)
 	const uint32_t grid = a.max_chunks < PERSISTENT_GRID ? a.max_chunks : PERSISTENT_GRID;

@@ -144,6 +144,34 @@ struct DecodeArgs {
 	uint32_t max_htiles;
 };
 
+// zstd frames on the device (press_zstd.hip, zs_table.h): scratch of one batch
+struct ZsRead {               // per read
+	uint32_t nk, nd;      // key bytes / data bytes of the svb-zd stream
+	uint32_t knz;         // key bytes that are not zero
+	uint32_t mode;        // 0: RLE keys + Huffman data, 1: raw blocks, 2: failed
+	uint32_t dbase;       // frame offset of the first data block
+	uint32_t pad[3];
+};
+struct ZsBufs {
+	uint8_t *ztmp;        // the svb-zd streams between the two stages: [u32 n][keys][data] of read r at zoff[r]
+	uint64_t *zoff;       // [nreads + 1]
+	uint64_t *zoff4;      // [nreads + 1] zoff + 4: where the svb kernels write / read
+	uint64_t *zlen;       // [nreads] bytes of keys + data
+	uint32_t *hist;       // [nreads][256]
+	void *tab;            // zs::Table [nreads]
+	uint32_t *first_blk;  // [nreads + 1] id of the first data block of read r
+	uint32_t *blk_read;   // [max_blocks]
+	uint4 *sbits;         // [max_blocks] code bits of the four streams of a block
+	uint32_t *bpos;       // [max_blocks] frame offset of the block
+	uint8_t *bflag;       // [max_blocks] 1: Huffman, 2: carries the tree, 4: last block of the frame
+	uint32_t *kcnt;       // [max_chunks] non-zero key bytes in a chunk's keys
+	uint32_t *kbase;      // [max_chunks] ... in the chunks of the read in front of it
+	ZsRead *rd;           // [nreads]
+	uint32_t *nblocks;    // [1]
+	uint32_t max_blocks;
+};
+void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s); // press_zstd.hip
+
 // Optional timing of the dominant kernel of a batch call with HIP events recorded on the
 // launch stream (bench.py's roofline figure): launchers call these around that kernel.
 void ktime_begin(int which, hipStream_t s); // which: 0 = press, 1 = depress

@@ -1,0 +1,759 @@
+// press_zstd.hip - zstd frames made on the device (BASELINE config 3: the
+// "VBZ" pipeline zstd(svb-zd), press.c:1860 zstd_svb_zd_press_16).
+//
+// The reference gives the buffer [u32 n][svb32 keys][svb32 data] to libzstd.  What a drop-in
+// has to keep is the format (RFC 8878): every zstd decoder must return that buffer.  A frame
+// written here is laid out for a GPU on both sides - no sequences, only
+//   * one raw block with the count,
+//   * RLE blocks for the key bytes (they are zero except where a delta needs two bytes),
+//   * the data bytes in blocks of 16 KiB, Huffman-coded literals in four independent bit
+//     streams each, with ONE table per read (the first block carries the tree, the others are
+//     "treeless"), or raw where that does not pay,
+// i.e. ~60 independent streams of <= 4096 bytes per mean read.  zs_table.h builds the table.
+// tests/: libzstd decodes these frames to the reference's buffer; oracle/zsframe_model.cpp is a
+// serial model that must give the same bytes.
+//
+// Kernels (encode): k_zs_layout -> [svb encode into ztmp] -> k_zs_blocks -> k_zs_blockmap ->
+// k_zs_hist + k_zs_keycount -> k_zs_table -> k_zs_keylist + k_zs_bits -> k_zs_plan ->
+// k_zs_encode (+ k_zs_rawframes for reads that do not shrink).
+
+#include "press_internal.h"
+#include "zs_table.h"
+
+namespace ph {
+
+namespace {
+
+constexpr uint32_t ZB = zs::BLOCK_LITS;
+constexpr uint32_t RLE_MAX = 131072; // Block_Maximum_Size
+constexpr uint32_t KCH = CHUNK / 4;  // key bytes per chunk
+constexpr uint64_t ZFAIL = ~0ull;
+
+__device__ __forceinline__ uint64_t wave_incl64(uint64_t v, int lane)
+{
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint64_t o = __shfl_up(v, d);
+		if (lane >= d)
+			v += o;
+	}
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_incl32(uint32_t v, int lane)
+{
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t o = __shfl_up(v, d);
+		if (lane >= d)
+			v += o;
+	}
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v)
+{
+#pragma unroll
+	for (int d = 32; d; d >>= 1)
+		v += __shfl_xor(v, d);
+	return v;
+}
+
+// exclusive scan over a 1024-thread workgroup; *total = sum
+__device__ __forceinline__ uint64_t wg_excl_scan64(uint64_t v, uint64_t *wsum, uint64_t *total)
+{
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint64_t inc = wave_incl64(v, lane);
+	__syncthreads();
+	if (lane == 63)
+		wsum[w] = inc;
+	__syncthreads();
+	uint64_t before = 0, all = 0;
+	for (int i = 0; i < (int) (blockDim.x >> 6); i++) {
+		const uint64_t x = wsum[i];
+		if (i < w)
+			before += x;
+		all += x;
+	}
+	*total = all;
+	return before + inc - v;
+}
+
+__device__ __forceinline__ uint64_t zs_slot(uint32_t n)
+{
+	// [u32 n][keys][data]: a 16-bit zig-zag delta is at most two bytes
+	return ((4ull + (n + 3ull) / 4 + 2ull * n + 16) + 15) & ~15ull;
+}
+
+// where the svb-zd stream of every read goes in ztmp (one workgroup)
+__global__ __launch_bounds__(1024) void k_zs_layout(const uint32_t *nsamp, uint32_t nreads, uint64_t *zoff, uint64_t *zoff4)
+{
+	__shared__ uint64_t wsum[16];
+	uint64_t carry = 0;
+	for (uint32_t base = 0; base <= nreads; base += 1024) {
+		const uint32_t r = base + threadIdx.x;
+		const uint64_t v = r < nreads ? zs_slot(nsamp[r]) : 0;
+		uint64_t total;
+		const uint64_t ex = wg_excl_scan64(v, wsum, &total);
+		if (r <= nreads) {
+			zoff[r] = carry + ex;
+			zoff4[r] = carry + ex + 4;
+		}
+		carry += total;
+	}
+}
+
+// data blocks of every read (one workgroup): first_blk, the per-read record, the total
+__global__ __launch_bounds__(1024) void k_zs_blocks(const uint32_t *nsamp, const uint64_t *zlen, uint32_t nreads,
+						    uint32_t *first_blk, ZsRead *rd, uint32_t *nblocks, uint32_t max_blocks)
+{
+	__shared__ uint64_t wsum[16];
+	uint64_t carry = 0;
+	for (uint32_t base = 0; base <= nreads; base += 1024) {
+		const uint32_t r = base + threadIdx.x;
+		uint64_t nb = 0;
+		if (r < nreads) {
+			const uint32_t n = nsamp[r];
+			const uint64_t l = zlen[r];
+			ZsRead z;
+			z.nk = (uint32_t) (((uint64_t) n + 3) / 4);
+			z.mode = 0;
+			z.knz = 0;
+			z.dbase = 0;
+			z.pad[0] = z.pad[1] = z.pad[2] = 0;
+			if (l == ZFAIL || l < z.nk) {
+				z.nd = 0;
+				z.mode = 2;
+			} else {
+				z.nd = (uint32_t) (l - z.nk);
+			}
+			nb = z.mode == 0 ? (z.nd + ZB - 1) / ZB : 0;
+			rd[r] = z;
+		}
+		uint64_t total;
+		const uint64_t ex = wg_excl_scan64(nb, wsum, &total);
+		if (r <= nreads)
+			first_blk[r] = (uint32_t) (carry + ex < max_blocks ? carry + ex : max_blocks);
+		carry += total;
+	}
+	if (threadIdx.x == 0)
+		*nblocks = (uint32_t) (carry < max_blocks ? carry : max_blocks);
+}
+
+__global__ __launch_bounds__(256) void k_zs_blockmap(const uint32_t *first_blk, uint32_t nreads, const uint32_t *nblocks,
+						     uint32_t *blk_read)
+{
+	const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+	if (b >= *nblocks)
+		return;
+	uint32_t lo = 0, hi = nreads; // the last r with first_blk[r] <= b
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) / 2;
+		if (first_blk[mid] <= b)
+			lo = mid;
+		else
+			hi = mid;
+	}
+	blk_read[b] = lo;
+}
+
+struct BlkU {
+	uint32_t r, j, R;
+	const uint8_t *data; // the block's bytes in ztmp
+};
+__device__ __forceinline__ BlkU load_blk(const ZsBufs &z, uint32_t b)
+{
+	BlkU u;
+	u.r = z.blk_read[b];
+	u.j = b - z.first_blk[u.r];
+	const ZsRead *rd = z.rd + u.r;
+	const uint32_t nd = rd->nd;
+	u.R = nd - u.j * ZB < ZB ? nd - u.j * ZB : ZB;
+	u.data = z.ztmp + z.zoff[u.r] + 4 + rd->nk + (uint64_t) u.j * ZB;
+	return u;
+}
+
+// byte histogram of one data block, added to the read's
+__global__ __launch_bounds__(256) void k_zs_hist(ZsBufs z)
+{
+	__shared__ uint32_t h[4][256];
+	const uint32_t b = blockIdx.x;
+	if (b >= *z.nblocks)
+		return;
+	const BlkU u = load_blk(z, b);
+	const int w = threadIdx.x >> 6;
+	for (int i = 0; i < 4; i++)
+		h[i][threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t i0 = threadIdx.x * 64;
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		const uint32_t at = i0 + 16 * q;
+		if (at + 16 <= u.R) {
+			uint4 v;
+			__builtin_memcpy(&v, u.data + at, 16);
+			const uint32_t x[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+			for (int d = 0; d < 4; d++)
+#pragma unroll
+				for (int e = 0; e < 4; e++)
+					atomicAdd(&h[w][(x[d] >> (8 * e)) & 0xFFu], 1u);
+		} else {
+			for (uint32_t e = at; e < u.R && e < at + 16; e++)
+				atomicAdd(&h[w][u.data[e]], 1u);
+		}
+	}
+	__syncthreads();
+	const uint32_t c = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+	if (c)
+		atomicAdd(&z.hist[(uint64_t) u.r * 256 + threadIdx.x], c);
+}
+
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x)
+{
+	return (uint32_t) __builtin_popcount((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u);
+}
+
+// key bytes of chunk c of its read that are not zero; thread t looks at 32 of them
+__device__ __forceinline__ uint32_t key_load(const ZsBufs &z, const ChunkDesc *dp, uint32_t *x, uint32_t *first)
+{
+	const uint32_t r = dp->read, j = dp->j;
+	const uint32_t nk = z.rd[r].nk;
+	const uint8_t *keys = z.ztmp + z.zoff[r] + 4;
+	const uint32_t k0 = j * KCH + threadIdx.x * 32;
+	*first = k0;
+	uint32_t cnt = 0;
+#pragma unroll
+	for (int q = 0; q < 2; q++) {
+		const uint32_t at = k0 + 16 * q;
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (at + 16 <= nk) {
+			__builtin_memcpy(&v, keys + at, 16);
+		} else if (at < nk) {
+			uint8_t tmp[16] = { 0 };
+			for (uint32_t e = 0; e < nk - at; e++)
+				tmp[e] = keys[at + e];
+			__builtin_memcpy(&v, tmp, 16);
+		}
+		x[4 * q] = v.x;
+		x[4 * q + 1] = v.y;
+		x[4 * q + 2] = v.z;
+		x[4 * q + 3] = v.w;
+		cnt += nonzero_bytes(v.x) + nonzero_bytes(v.y) + nonzero_bytes(v.z) + nonzero_bytes(v.w);
+	}
+	return cnt;
+}
+
+__global__ __launch_bounds__(256) void k_zs_keycount(BatchArgs a, ZsBufs z)
+{
+	__shared__ uint32_t ws[4];
+	const uint32_t c = blockIdx.x;
+	if (c >= a.ctl->nchunks)
+		return;
+	const ChunkDesc *dp = a.chunks + c;
+	if (z.rd[dp->read].mode) {
+		if (threadIdx.x == 0)
+			z.kcnt[c] = 0;
+		return;
+	}
+	uint32_t x[8], first;
+	const uint32_t cnt = wave_sum32(key_load(z, dp, x, &first));
+	if ((threadIdx.x & 63) == 0)
+		ws[threadIdx.x >> 6] = cnt;
+	__syncthreads();
+	if (threadIdx.x == 0)
+		z.kcnt[c] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// the non-zero key bytes of a read in order: position in ex_pos[off[r] + rank], value in ex_val
+__global__ __launch_bounds__(256) void k_zs_keylist(BatchArgs a, ZsBufs z)
+{
+	__shared__ uint32_t ws[4];
+	const uint32_t c = blockIdx.x;
+	if (c >= a.ctl->nchunks || z.kcnt[c] == 0)
+		return;
+	const ChunkDesc *dp = a.chunks + c;
+	uint32_t x[8], first;
+	const uint32_t cnt = key_load(z, dp, x, &first);
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint32_t inc = wave_incl32(cnt, lane);
+	if (lane == 63)
+		ws[w] = inc;
+	__syncthreads();
+	uint32_t rank = z.kbase[c] + inc - cnt;
+	for (int i = 0; i < w; i++)
+		rank += ws[i];
+	if (!cnt)
+		return;
+	const uint64_t base = a.off[dp->read];
+	for (int e = 0; e < 32; e++) {
+		const uint32_t v = (x[e >> 2] >> (8 * (e & 3))) & 0xFFu;
+		if (v) {
+			a.ex_pos[base + rank] = first + e;
+			a.ex_val[base + rank] = v;
+			rank++;
+		}
+	}
+}
+
+// one wave per read: the Huffman table from the histogram, and the ranks of the key lists
+struct TabLds {
+	uint32_t cnt[256];
+	uint8_t order[256];
+	zs::Table t;
+	zs::Work k;
+};
+__global__ __launch_bounds__(256) void k_zs_table(BatchArgs a, ZsBufs z)
+{
+	__shared__ TabLds lds[4];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const uint32_t r = blockIdx.x * 4 + w;
+	if (r >= a.nreads)
+		return;
+	ZsRead *rd = z.rd + r;
+	if (rd->mode)
+		return;
+	TabLds &L = lds[w];
+	// ---- ranks of the key lists
+	{
+		const uint32_t n = a.nsamp[r];
+		const uint32_t nch = (n + CHUNK - 1) / CHUNK, c0 = a.first_chunk[r];
+		uint32_t carry = 0;
+		for (uint32_t i = 0; i < nch; i += 64) {
+			const uint32_t v = i + lane < nch ? z.kcnt[c0 + i + lane] : 0;
+			const uint32_t inc = wave_incl32(v, lane);
+			if (i + lane < nch)
+				z.kbase[c0 + i + lane] = carry + inc - v;
+			carry += __shfl(inc, 63);
+		}
+		if (lane == 0)
+			rd->knz = carry;
+	}
+	// ---- the table
+	uint32_t mine[4], present = 0;
+	for (int i = 0; i < 4; i++) {
+		mine[i] = z.hist[(uint64_t) r * 256 + lane + 64 * i];
+		present += mine[i] != 0;
+	}
+	present = wave_sum32(present);
+	zs::Table *gt = (zs::Table *) z.tab + r;
+	if (present == 0) {
+		if (lane == 0)
+			gt->ok = 0;
+		return;
+	}
+	if (present == 1) { // a lone byte value gets a partner (zsframe_model.cpp)
+		const uint32_t zero_has = __shfl(mine[0], 0);
+		if (lane == (zero_has ? 1 : 0))
+			mine[0] = 1;
+		present = 2;
+	}
+	for (int i = 0; i < 4; i++)
+		L.cnt[lane + 64 * i] = mine[i];
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	uint32_t rank[4] = { 0, 0, 0, 0 };
+	for (uint32_t s = 0; s < 256; s++) {
+		const uint32_t c = L.cnt[s];
+		if (!c)
+			continue;
+		for (int i = 0; i < 4; i++) {
+			const uint32_t me = lane + 64 * i;
+			rank[i] += c < mine[i] || (c == mine[i] && s < me);
+		}
+	}
+	for (int i = 0; i < 4; i++)
+		if (mine[i])
+			L.order[rank[i]] = (uint8_t) (lane + 64 * i);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	if (lane == 0)
+		zs::build_table(L.cnt, L.order, present, L.t, L.k);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	const uint32_t *src = (const uint32_t *) &L.t;
+	uint32_t *dst = (uint32_t *) gt;
+	for (uint32_t i = lane; i < sizeof(zs::Table) / 4; i += 64)
+		dst[i] = src[i];
+}
+
+// code bits of the four streams of a data block
+__global__ __launch_bounds__(256) void k_zs_bits(ZsBufs z)
+{
+	__shared__ uint8_t len[256];
+	const uint32_t b = blockIdx.x;
+	if (b >= *z.nblocks)
+		return;
+	const BlkU u = load_blk(z, b);
+	const zs::Table *t = (const zs::Table *) z.tab + u.r;
+	if (!t->ok || u.R < zs::MIN_HUF_LITS) {
+		if (threadIdx.x == 0)
+			z.sbits[b] = make_uint4(0, 0, 0, 0);
+		return;
+	}
+	len[threadIdx.x] = t->len[threadIdx.x];
+	__syncthreads();
+	const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+	const uint32_t seg = (u.R + 3) / 4;
+	const uint32_t k = q < 3 ? seg : u.R - 3 * seg;
+	const uint8_t *s = u.data + (uint64_t) q * seg;
+	uint32_t bits = 0;
+	for (uint32_t i0 = lane * 16; i0 < k; i0 += 1024) {
+		if (i0 + 16 <= k) {
+			uint4 v;
+			__builtin_memcpy(&v, s + i0, 16);
+			const uint32_t x[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+			for (int d = 0; d < 4; d++)
+#pragma unroll
+				for (int e = 0; e < 4; e++)
+					bits += len[(x[d] >> (8 * e)) & 0xFFu];
+		} else {
+			for (uint32_t e = i0; e < k; e++)
+				bits += len[s[e]];
+		}
+	}
+	bits = wave_sum32(bits);
+	__shared__ uint32_t qb[4];
+	if (lane == 0)
+		qb[q] = bits;
+	__syncthreads();
+	if (threadIdx.x == 0)
+		z.sbits[b] = make_uint4(qb[0], qb[1], qb[2], qb[3]);
+}
+
+__device__ __forceinline__ void put_block_header(uint8_t *p, bool last, uint32_t type, uint32_t size)
+{
+	const uint32_t h = (last ? 1u : 0u) | (type << 1) | (size << 3);
+	p[0] = (uint8_t) h;
+	p[1] = (uint8_t) (h >> 8);
+	p[2] = (uint8_t) (h >> 16);
+}
+__device__ __forceinline__ void put_rle(uint8_t *p, uint32_t len, uint8_t v)
+{
+	put_block_header(p, false, 1, len);
+	p[3] = v;
+}
+
+// bytes of the Huffman streams of a block (without the tree): jump table + four streams
+__device__ __forceinline__ uint32_t huf_size(uint4 sb)
+{
+	return 6 + (sb.x / 8 + 1) + (sb.y / 8 + 1) + (sb.z / 8 + 1) + (sb.w / 8 + 1);
+}
+
+// one wave per read: the plan of the frame - key blocks written, data blocks placed
+__global__ __launch_bounds__(256) void k_zs_plan(BatchArgs a, ZsBufs z)
+{
+	const int lane = threadIdx.x & 63;
+	const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= a.nreads)
+		return;
+	ZsRead *rd = z.rd + r;
+	if (rd->mode) {
+		if (lane == 0)
+			a.out_len[r] = ZFAIL;
+		return;
+	}
+	const uint32_t n = a.nsamp[r];
+	const uint32_t nk = rd->nk, nd = rd->nd, knz = rd->knz;
+	const uint64_t L = 4ull + nk + nd;
+	const uint64_t cap = a.out_off[r + 1] - a.out_off[r];
+	uint8_t *out = a.out + a.out_off[r];
+	const uint32_t *kpos = a.ex_pos + a.off[r];
+	const uint32_t *kval = a.ex_val + a.off[r];
+	const zs::Table *t = (const zs::Table *) z.tab + r;
+	const uint32_t b0 = z.first_blk[r], nblk = (nd + ZB - 1) / ZB;
+	const uint32_t desc_len = t->ok ? t->desc_len : 0;
+
+	// ---- key blocks: a run of zeros (pieces of at most 128 KiB) in front of every other key byte
+	uint32_t nkb = 0;
+	for (uint32_t i = 0; i < knz; i += 64) {
+		uint32_t blocks = 0;
+		if (i + lane < knz) {
+			const uint32_t p = kpos[i + lane];
+			const uint32_t gap = i + lane ? p - kpos[i + lane - 1] - 1 : p;
+			blocks = (gap + RLE_MAX - 1) / RLE_MAX + 1;
+		}
+		nkb += wave_sum32(blocks);
+	}
+	const uint32_t tail = knz ? nk - 1 - kpos[knz - 1] : nk;
+	nkb += (tail + RLE_MAX - 1) / RLE_MAX;
+	const uint32_t dbase = 9 + 7 + 4 * nkb;
+
+	// ---- data blocks: the first one that pays WITH the tree carries it
+	uint32_t F = 0xFFFFFFFFu;
+	if (t->ok) {
+		for (uint32_t i = 0; i < nblk && F == 0xFFFFFFFFu; i += 64) {
+			bool cand = false;
+			if (i + lane < nblk) {
+				const uint32_t R = nd - (i + lane) * ZB < ZB ? nd - (i + lane) * ZB : ZB;
+				const uint4 sb = z.sbits[b0 + i + lane];
+				const uint32_t hs = huf_size(sb);
+				cand = R >= zs::MIN_HUF_LITS && 6 + desc_len + hs < R && sb.x / 8 + 1 < 65536 && sb.y / 8 + 1 < 65536 &&
+				       sb.z / 8 + 1 < 65536;
+			}
+			const unsigned long long m = __ballot(cand);
+			if (m)
+				F = i + (uint32_t) __builtin_ctzll(m);
+		}
+	}
+	uint64_t total = dbase;
+	for (uint32_t i = 0; i < nblk; i += 64) {
+		uint32_t size = 0, flag = 0;
+		if (i + lane < nblk) {
+			const uint32_t bi = i + lane;
+			const uint32_t R = nd - bi * ZB < ZB ? nd - bi * ZB : ZB;
+			const uint4 sb = z.sbits[b0 + bi];
+			const uint32_t hs = huf_size(sb);
+			bool huf = false;
+			if (bi == F)
+				huf = true;
+			else if (bi > F && F != 0xFFFFFFFFu)
+				huf = R >= zs::MIN_HUF_LITS && 6 + hs < R;
+			if (huf) {
+				flag = 1u | (bi == F ? 2u : 0u);
+				size = 3 + 5 + (bi == F ? desc_len : 0) + hs + 1;
+			} else {
+				size = 3 + R;
+			}
+			if (bi + 1 == nblk)
+				flag |= 4u;
+		}
+		const uint64_t inc = wave_incl64(size, lane);
+		if (i + lane < nblk) {
+			z.bpos[b0 + i + lane] = (uint32_t) (total + inc - size);
+			z.bflag[b0 + i + lane] = (uint8_t) flag;
+		}
+		total += __shfl(inc, 63);
+	}
+	const uint64_t raw_total = 9 + L + 3 * ((L + RLE_MAX - 1) / RLE_MAX);
+	uint32_t mode = 0;
+	uint64_t size = total;
+	if (total >= raw_total) {
+		mode = 1;
+		size = raw_total;
+	}
+	if (size > cap) {
+		mode = 2;
+		size = ZFAIL;
+	}
+	if (lane == 0) {
+		rd->mode = mode;
+		rd->dbase = dbase;
+		a.out_len[r] = size;
+	}
+	if (mode)
+		return;
+	// ---- frame header, the count, the key blocks
+	if (lane == 0) {
+		out[0] = 0x28;
+		out[1] = 0xB5;
+		out[2] = 0x2F;
+		out[3] = 0xFD;
+		out[4] = 0xA0; // single segment, 4-byte content size
+		out[5] = (uint8_t) L;
+		out[6] = (uint8_t) (L >> 8);
+		out[7] = (uint8_t) (L >> 16);
+		out[8] = (uint8_t) (L >> 24);
+		put_block_header(out + 9, nk == 0 && nd == 0, 0, 4);
+		out[12] = (uint8_t) n;
+		out[13] = (uint8_t) (n >> 8);
+		out[14] = (uint8_t) (n >> 16);
+		out[15] = (uint8_t) (n >> 24);
+	}
+	uint32_t kb = 0; // key blocks in front
+	for (uint32_t i = 0; i < knz; i += 64) {
+		uint32_t blocks = 0, gap = 0;
+		if (i + lane < knz) {
+			const uint32_t p = kpos[i + lane];
+			gap = i + lane ? p - kpos[i + lane - 1] - 1 : p;
+			blocks = (gap + RLE_MAX - 1) / RLE_MAX + 1;
+		}
+		const uint32_t inc = wave_incl32(blocks, lane);
+		if (i + lane < knz) {
+			uint8_t *p = out + 16 + 4ull * (kb + inc - blocks);
+			for (uint32_t at = 0; at < gap; at += RLE_MAX, p += 4)
+				put_rle(p, gap - at < RLE_MAX ? gap - at : RLE_MAX, 0);
+			put_rle(p, 1, (uint8_t) kval[i + lane]);
+		}
+		kb += __shfl(inc, 63);
+	}
+	if (lane == 0) {
+		uint8_t *p = out + 16 + 4ull * kb;
+		for (uint32_t at = 0; at < tail; at += RLE_MAX, p += 4)
+			put_rle(p, tail - at < RLE_MAX ? tail - at : RLE_MAX, 0);
+	}
+}
+
+// one workgroup per data block, one wave per bit stream
+constexpr int ZSTG = 1416; // dwords: 4096 codes of at most 11 bits + the end mark
+__global__ __launch_bounds__(256) void k_zs_encode(BatchArgs a, ZsBufs z)
+{
+	__shared__ uint32_t enc[256];       // code | len << 16
+	__shared__ uint32_t stg_all[4][ZSTG];
+	__shared__ __attribute__((aligned(16))) uint8_t lit[4][4096];
+	const uint32_t b = blockIdx.x;
+	if (b >= *z.nblocks)
+		return;
+	const BlkU u = load_blk(z, b);
+	if (z.rd[u.r].mode)
+		return;
+	const uint32_t flag = z.bflag[b];
+	uint8_t *blk = a.out + a.out_off[u.r] + z.bpos[b];
+	const bool last = flag & 4u;
+	if (!(flag & 1u)) { // raw block
+		if (threadIdx.x == 0)
+			put_block_header(blk, last, 0, u.R);
+		for (uint32_t i = threadIdx.x; i < u.R; i += 256)
+			blk[3 + i] = u.data[i];
+		return;
+	}
+	const zs::Table *t = (const zs::Table *) z.tab + u.r;
+	enc[threadIdx.x] = (uint32_t) t->code[threadIdx.x] | ((uint32_t) t->len[threadIdx.x] << 16);
+	const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+	uint32_t *stg = stg_all[q];
+	for (int i = lane; i < ZSTG; i += 64)
+		stg[i] = 0;
+	const uint32_t seg = (u.R + 3) / 4;
+	const uint32_t k = q < 3 ? seg : u.R - 3 * seg;
+	{ // the stream's bytes into LDS, 16 per lane and step
+		const uint8_t *s = u.data + (uint64_t) q * seg;
+		for (uint32_t i0 = lane * 16; i0 < k; i0 += 1024) {
+			if (i0 + 16 <= k) {
+				uint4 v;
+				__builtin_memcpy(&v, s + i0, 16);
+				*reinterpret_cast<uint4 *>(&lit[q][i0]) = v;
+			} else {
+				for (uint32_t e = i0; e < k; e++)
+					lit[q][e] = s[e];
+			}
+		}
+	}
+	__syncthreads();
+	const uint4 sb = z.sbits[b];
+	const uint32_t sbq[4] = { sb.x, sb.y, sb.z, sb.w };
+	const uint32_t desc_len = (flag & 2u) ? t->desc_len : 0;
+	const uint32_t body = desc_len + huf_size(sb);
+	uint8_t *p = blk + 3 + 5 + desc_len; // the jump table
+	if (threadIdx.x == 0) {
+		put_block_header(blk, last, 2, 5 + body + 1);
+		const uint64_t lh = ((flag & 2u) ? 2u : 3u) | (3u << 2) | ((uint64_t) u.R << 4) | ((uint64_t) body << 22);
+		for (int i = 0; i < 5; i++)
+			blk[3 + i] = (uint8_t) (lh >> (8 * i));
+		for (int i = 0; i < 3; i++) {
+			const uint32_t sz = sbq[i] / 8 + 1;
+			p[2 * i] = (uint8_t) sz;
+			p[2 * i + 1] = (uint8_t) (sz >> 8);
+		}
+		blk[3 + 5 + body] = 0; // no sequences
+	}
+	if (desc_len)
+		for (uint32_t i = threadIdx.x; i < desc_len; i += 256)
+			blk[8 + i] = t->desc[i];
+	// ---- the stream: the bytes back to front, the first byte's code on top, then the end mark.
+	// A lane packs its contiguous run of codes in a register and ORs whole dwords into LDS.
+	const uint32_t c = (k + 63) / 64;
+	const uint32_t lo = lane * c < k ? lane * c : k, hi = lo + c < k ? lo + c : k;
+	uint32_t mybits = 0;
+	for (uint32_t i = lo; i < hi; i++)
+		mybits += enc[lit[q][i]] >> 16;
+	const uint32_t inc = wave_incl32(mybits, lane);
+	const uint32_t totalb = __shfl(inc, 63);
+	uint32_t pos = totalb - inc; // bits of the lanes behind this one
+	{
+		uint64_t acc = 0;
+		uint32_t nb = pos & 31u, wd = pos >> 5;
+		for (uint32_t i = hi; i-- > lo;) {
+			const uint32_t e = enc[lit[q][i]];
+			acc |= (uint64_t) (e & 0xFFFFu) << nb;
+			nb += e >> 16;
+			if (nb >= 32) {
+				atomicOr(&stg[wd++], (uint32_t) acc);
+				acc >>= 32;
+				nb -= 32;
+			}
+		}
+		if (lane == 0) { // the end mark sits on top of the first byte's code
+			acc |= 1ull << nb;
+			nb++;
+		}
+		if (nb)
+			atomicOr(&stg[wd], (uint32_t) acc);
+		if (nb > 32)
+			atomicOr(&stg[wd + 1], (uint32_t) (acc >> 32));
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	uint8_t *dst = p + 6;
+	for (int i = 0; i < q; i++)
+		dst += sbq[i] / 8 + 1;
+	const uint32_t bytes = totalb / 8 + 1;
+	for (uint32_t i = lane; i < bytes / 4; i += 64) {
+		const uint32_t v = stg[i];
+		__builtin_memcpy(dst + 4ull * i, &v, 4);
+	}
+	if (lane < (int) (bytes & 3u)) {
+		const uint32_t at = (bytes & ~3u) + lane;
+		dst[at] = (uint8_t) (stg[at >> 2] >> (8 * (at & 3)));
+	}
+}
+
+// reads that do not shrink: the stream in raw blocks of 128 KiB
+__global__ __launch_bounds__(256) void k_zs_rawframes(BatchArgs a, ZsBufs z)
+{
+	const uint32_t r = blockIdx.x;
+	if (z.rd[r].mode != 1)
+		return;
+	const uint32_t n = a.nsamp[r];
+	const uint64_t L = 4ull + z.rd[r].nk + z.rd[r].nd;
+	uint8_t *out = a.out + a.out_off[r];
+	const uint8_t *S = z.ztmp + z.zoff[r];
+	if (threadIdx.x == 0) {
+		out[0] = 0x28;
+		out[1] = 0xB5;
+		out[2] = 0x2F;
+		out[3] = 0xFD;
+		out[4] = 0xA0;
+		for (int i = 0; i < 4; i++)
+			out[5 + i] = (uint8_t) (L >> (8 * i));
+		for (uint64_t at = 0; at < L; at += RLE_MAX) {
+			const uint64_t len = L - at < RLE_MAX ? L - at : RLE_MAX;
+			put_block_header(out + 9 + at + 3 * (at / RLE_MAX), at + len == L, 0, (uint32_t) len);
+		}
+	}
+	for (uint64_t i = threadIdx.x; i < L; i += 256) {
+		const uint8_t v = i < 4 ? (uint8_t) (n >> (8 * i)) : S[i];
+		out[9 + 3 * (i / RLE_MAX + 1) + i] = v;
+	}
+}
+
+} // namespace
+
+void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
+{
+	if (!a.nreads)
+		return;
+	hipLaunchKernelGGL(k_zs_layout, dim3(1), dim3(1024), 0, s, a.nsamp, a.nreads, z.zoff, z.zoff4);
+	BatchArgs sv = a; // the svb-zd stream of every read into ztmp, behind the place of its count
+	sv.out = z.ztmp;
+	sv.out_off = z.zoff4;
+	sv.out_len = z.zlen;
+	launch_svb_encode_chunked(sv, true, true, s);
+	hipLaunchKernelGGL(k_zs_blocks, dim3(1), dim3(1024), 0, s, a.nsamp, z.zlen, a.nreads, z.first_blk, z.rd, z.nblocks,
+			   z.max_blocks);
+	hipLaunchKernelGGL(k_zs_blockmap, dim3((z.max_blocks + 255) / 256), dim3(256), 0, s, z.first_blk, a.nreads, z.nblocks,
+			   z.blk_read);
+	(void) hipMemsetAsync(z.hist, 0, (size_t) a.nreads * 1024, s);
+	hipLaunchKernelGGL(k_zs_hist, dim3(z.max_blocks), dim3(256), 0, s, z);
+	hipLaunchKernelGGL(k_zs_keycount, dim3(a.max_chunks), dim3(256), 0, s, a, z);
+	hipLaunchKernelGGL(k_zs_table, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
+	hipLaunchKernelGGL(k_zs_keylist, dim3(a.max_chunks), dim3(256), 0, s, a, z);
+	hipLaunchKernelGGL(k_zs_bits, dim3(z.max_blocks), dim3(256), 0, s, z);
+	hipLaunchKernelGGL(k_zs_plan, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
+	hipLaunchKernelGGL(k_zs_encode, dim3(z.max_blocks), dim3(256), 0, s, a, z);
+	hipLaunchKernelGGL(k_zs_rawframes, dim3(a.nreads), dim3(256), 0, s, a, z);
+}
+
+} // namespace ph

@@ -1,0 +1,195 @@
+// zsframe_model.cpp - TEST INFRASTRUCTURE ONLY.  A serial CPU model of the zstd frame writer of
+// honours_amd/csrc/press_zstd.hip.  Not a restatement of the reference - the
+// reference hands the svb-zd stream to libzstd (press.c:1865) and any valid zstd frame of that
+// stream is a correct result.  The tests use this model two ways: libzstd must decode what it
+// writes back to the stream (here, without a GPU), and the device must write the same bytes.
+// The table construction is the product's own header (zs_table.h), compiled for the host.
+#include "../honours_amd/csrc/zs_table.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct Out {
+	uint8_t *p;
+	uint64_t cap, pos;
+	bool over;
+	void put(const void *s, uint64_t n)
+	{
+		if (pos + n > cap)
+			over = true;
+		else
+			memcpy(p + pos, s, n);
+		pos += n;
+	}
+	void block_header(bool last, uint32_t type, uint32_t size)
+	{
+		const uint32_t h = (last ? 1u : 0u) | (type << 1) | (size << 3);
+		put(&h, 3);
+	}
+};
+
+void frame_header(Out &o, uint64_t L)
+{
+	const uint8_t h[5] = { 0x28, 0xB5, 0x2F, 0xFD, 0xA0 }; // magic; single segment, 4-byte content size
+	o.put(h, 5);
+	const uint32_t l = (uint32_t) L;
+	o.put(&l, 4);
+}
+
+uint64_t raw_frame(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap)
+{
+	Out o{ out, cap, 0, false };
+	frame_header(o, L);
+	uint64_t at = 0;
+	do {
+		const uint64_t len = std::min<uint64_t>(L - at, 131072);
+		o.block_header(at + len == L, 0, (uint32_t) len);
+		o.put(S + at, len);
+		at += len;
+	} while (at < L);
+	return o.over ? 0 : o.pos;
+}
+
+// one bit stream: the bytes back to front, the first byte's code on top, then the end mark
+uint32_t stream_bits(const zs::Table &t, const uint8_t *s, uint32_t k)
+{
+	uint32_t bits = 0;
+	for (uint32_t i = 0; i < k; i++)
+		bits += t.len[s[i]];
+	return bits;
+}
+void stream_write(const zs::Table &t, const uint8_t *s, uint32_t k, std::vector<uint8_t> &dst)
+{
+	const uint32_t bits = stream_bits(t, s, k);
+	const size_t base = dst.size();
+	dst.resize(base + bits / 8 + 1, 0);
+	uint32_t pos = 0;
+	for (uint32_t i = k; i-- > 0;) {
+		const uint32_t c = t.code[s[i]], l = t.len[s[i]];
+		for (uint32_t b = 0; b < l; b++, pos++)
+			if ((c >> b) & 1u)
+				dst[base + (pos >> 3)] |= (uint8_t) (1u << (pos & 7));
+	}
+	dst[base + (pos >> 3)] |= (uint8_t) (1u << (pos & 7));
+}
+
+} // namespace
+
+extern "C" {
+
+// cnt[256] -> table (for direct tests of zs_table.h); returns t.ok
+int zsm_table(const uint32_t *cnt, zs::Table *t)
+{
+	uint8_t order[256];
+	uint32_t m = 0;
+	for (int s = 0; s < 256; s++)
+		if (cnt[s])
+			order[m++] = (uint8_t) s;
+	std::sort(order, order + m, [&](uint8_t a, uint8_t b) { return cnt[a] != cnt[b] ? cnt[a] < cnt[b] : a < b; });
+	zs::Work k;
+	zs::build_table(cnt, order, m, *t, k);
+	return (int) t->ok;
+}
+
+// S = [u32 n][keys (n+3)/4][data] (the buffer the reference gives to ZSTD_compress, press.c:1860)
+// -> frame; returns its size, 0 when it does not fit
+uint64_t zsm_frame(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap)
+{
+	if (L < 4)
+		return raw_frame(S, L, out, cap);
+	uint32_t n;
+	memcpy(&n, S, 4);
+	const uint64_t nk = ((uint64_t) n + 3) / 4;
+	if (4 + nk > L)
+		return raw_frame(S, L, out, cap);
+	const uint8_t *keys = S + 4, *data = S + 4 + nk;
+	const uint64_t nd = L - 4 - nk;
+
+	// the table of this read: every data byte counts; a lone byte value gets a partner
+	uint32_t cnt[256] = { 0 };
+	for (uint64_t i = 0; i < nd; i++)
+		cnt[data[i]]++;
+	uint32_t distinct = 0;
+	for (int s = 0; s < 256; s++)
+		distinct += cnt[s] != 0;
+	if (distinct == 1)
+		cnt[cnt[0] ? 1 : 0] = 1;
+	zs::Table t;
+	memset(&t, 0, sizeof t);
+	if (distinct)
+		zsm_table(cnt, &t);
+
+	std::vector<uint8_t> buf(L + L / 1000 + 4096);
+	Out o{ buf.data(), buf.size(), 0, false };
+	frame_header(o, L);
+	const uint64_t nblocks = (nd + zs::BLOCK_LITS - 1) / zs::BLOCK_LITS;
+	// the count
+	o.block_header(nk == 0 && nd == 0, 0, 4);
+	o.put(S, 4);
+	// the keys: runs of zeros as RLE blocks of at most 128 KiB, every other key byte on its own
+	for (uint64_t i = 0; i < nk;) {
+		uint64_t j = i;
+		uint8_t v = keys[i];
+		if (v == 0) {
+			while (j < nk && keys[j] == 0 && j - i < 131072)
+				j++;
+		} else {
+			j = i + 1;
+		}
+		o.block_header(j == nk && nd == 0, 1, (uint32_t) (j - i));
+		o.put(&v, 1);
+		i = j;
+	}
+	// the data: 16 KiB blocks, four streams each
+	bool have_tree = false;
+	for (uint64_t bidx = 0; bidx < nblocks; bidx++) {
+		const uint8_t *lit = data + bidx * zs::BLOCK_LITS;
+		const uint32_t R = (uint32_t) std::min<uint64_t>(zs::BLOCK_LITS, nd - bidx * zs::BLOCK_LITS);
+		const bool last = bidx + 1 == nblocks;
+		bool huf = t.ok && R >= zs::MIN_HUF_LITS;
+		std::vector<uint8_t> body;
+		if (huf) {
+			const uint32_t seg = (R + 3) / 4;
+			uint32_t sz[4];
+			if (!have_tree)
+				body.insert(body.end(), t.desc, t.desc + t.desc_len);
+			const size_t jump = body.size();
+			body.resize(jump + 6);
+			for (int q = 0; q < 4; q++) {
+				const uint32_t k = q < 3 ? seg : R - 3 * seg;
+				const size_t before = body.size();
+				stream_write(t, lit + q * seg, k, body);
+				sz[q] = (uint32_t) (body.size() - before);
+			}
+			for (int q = 0; q < 3; q++) {
+				body[jump + 2 * q] = (uint8_t) sz[q];
+				body[jump + 2 * q + 1] = (uint8_t) (sz[q] >> 8);
+			}
+			huf = 6 + body.size() < R && sz[0] < 65536 && sz[1] < 65536 && sz[2] < 65536;
+		}
+		if (huf) {
+			o.block_header(last, 2, (uint32_t) (5 + body.size() + 1));
+			// literals section header: type (2: with tree, 3: treeless), size format 3 (18 + 18 bits)
+			const uint64_t lh = (have_tree ? 3u : 2u) | (3u << 2) | ((uint64_t) R << 4) | ((uint64_t) body.size() << 22);
+			o.put(&lh, 5);
+			o.put(body.data(), body.size());
+			const uint8_t noseq = 0;
+			o.put(&noseq, 1);
+			have_tree = true;
+		} else {
+			o.block_header(last, 0, R);
+			o.put(lit, R);
+		}
+	}
+	const uint64_t raw = 9 + L + 3 * ((L + 131071) / 131072);
+	if (o.over || o.pos >= raw)
+		return raw_frame(S, L, out, cap);
+	if (o.pos > cap)
+		return 0;
+	memcpy(out, buf.data(), o.pos);
+	return o.pos;
+}
+
+} // extern "C"

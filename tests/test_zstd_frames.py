@@ -1,0 +1,197 @@
+"""zstd frames made on the device (batch method zstd_svb_zd).
+
+What pins them: any zstd decoder must turn a frame into the buffer the reference gives to
+ZSTD_compress (press.c:1860: [u32 n][svb-zd stream]).  The compressed BYTES are free - the
+reference's own depend on the libzstd version ("parity unpinned").
+
+* CPU: oracle/zsframe_model.cpp (a serial model of the device writer, built on the product's
+  table code zs_table.h) -> libzstd must decode every frame; ratio against libzstd level 1.
+* GPU: the device writes the model's bytes; libzstd and the oracle's zstd_svb_zd decoder (the
+  reference's, when built) read them; the device reads them back.
+"""
+import ctypes
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import _libs
+from honours_amd import synth
+
+ROOT = _libs.ROOT
+MODEL_SRC = os.path.join(ROOT, "oracle", "zsframe_model.cpp")
+MODEL_SO = os.path.join(ROOT, "oracle", "libzsframe_model.so")
+
+
+def _zstd():
+    for name in ("/opt/conda/lib/libzstd.so.1", "libzstd.so.1", "libzstd.so"):
+        try:
+            z = ctypes.CDLL(name)
+        except OSError:
+            continue
+        z.ZSTD_decompress.restype = ctypes.c_size_t
+        z.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+        z.ZSTD_compress.restype = ctypes.c_size_t
+        z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        z.ZSTD_isError.argtypes = [ctypes.c_size_t]
+        return z
+    pytest.skip("no libzstd")
+
+
+def zstd_decode(z, frame, cap):
+    a = np.frombuffer(frame, dtype=np.uint8).copy()
+    out = np.zeros(cap + 64, dtype=np.uint8)
+    r = z.ZSTD_decompress(out.ctypes.data, cap + 64, a.ctypes.data, len(frame))
+    assert not z.ZSTD_isError(r), "libzstd refuses the frame"
+    return out[:r].tobytes()
+
+
+def zstd_level1(z, buf):
+    a = np.frombuffer(buf, dtype=np.uint8).copy()
+    out = np.zeros(len(buf) + len(buf) // 100 + 1024, dtype=np.uint8)
+    r = z.ZSTD_compress(out.ctypes.data, out.size, a.ctypes.data, len(buf), 1)
+    assert not z.ZSTD_isError(r)
+    return int(r)
+
+
+@pytest.fixture(scope="module")
+def model():
+    if not os.path.exists(MODEL_SO) or os.path.getmtime(MODEL_SO) < max(
+            os.path.getmtime(MODEL_SRC), os.path.getmtime(os.path.join(ROOT, "honours_amd", "csrc", "zs_table.h"))):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "zsmodel"], check=True)
+    m = ctypes.CDLL(MODEL_SO)
+    m.zsm_frame.restype = ctypes.c_uint64
+    m.zsm_frame.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+
+    def frame(buf):
+        a = np.frombuffer(buf, dtype=np.uint8).copy()
+        out = np.zeros(len(buf) + len(buf) // 100 + 65536, dtype=np.uint8)
+        r = m.zsm_frame(a.ctypes.data, len(buf), out.ctypes.data, out.size)
+        assert r
+        return out[:r].tobytes()
+    return frame
+
+
+def prezstd(oracle, s):
+    """the buffer the reference hands to ZSTD_compress (press.c:1860)"""
+    ret, c = oracle.press("svb_zd", s)
+    assert ret == 0
+    return struct.pack("<I", len(s)) + c
+
+
+def cases():
+    rng = np.random.default_rng(11)
+    out = []
+    sig, off = synth.synth_batch(7, 0, 10)
+    for r in range(10):
+        out.append(sig[int(off[r]):int(off[r + 1])])
+    for n in (1, 2, 3, 4, 5, 63, 64, 65, 100, 1000, 4096, 16384 + 5, 70000, 140000):
+        out.append(rng.integers(300, 700, n).astype(np.int16))                    # noisy
+        out.append(np.full(n, 511, dtype=np.int16))                               # constant: one data byte value
+        out.append(rng.integers(-32768, 32767, n).astype(np.int16))               # incompressible, every key set
+        out.append((np.cumsum(rng.integers(-3, 4, n)) + 500).astype(np.int16))    # tiny alphabet
+        s = (np.cumsum(rng.integers(-20, 21, n)) + 500).astype(np.int16)          # spikes: scattered key bytes
+        s[rng.integers(0, n, max(1, n // 300))] += 3000
+        out.append(s)
+    return out
+
+
+def test_model_frames_decode_with_libzstd(model):
+    z = _zstd()
+    oracle = _libs.oracle()
+    raw = ours = theirs = 0
+    for k, s in enumerate(cases()):
+        buf = prezstd(oracle, s)
+        f = model(buf)
+        assert zstd_decode(z, f, len(buf)) == buf, "case %d (n=%d)" % (k, len(s))
+        assert len(f) <= 9 + len(buf) + 3 * ((len(buf) + 131071) // 131072)
+        if k < 10:  # the NA12878-like reads
+            raw += 2 * len(s)
+            ours += len(f)
+            theirs += zstd_level1(z, buf)
+    # within 0.5 % of libzstd level 1 (what the reference calls VBZ) on nanopore-like reads
+    assert raw / ours > 0.995 * raw / theirs, (raw / ours, raw / theirs)
+
+
+def test_table_is_a_complete_prefix_code(model):
+    """zs_table.h on random histograms: Kraft equality, lengths <= 11, canonical codes"""
+    m = ctypes.CDLL(MODEL_SO)
+
+    class T(ctypes.Structure):
+        _fields_ = [("code", ctypes.c_uint16 * 256), ("len", ctypes.c_uint8 * 256), ("desc", ctypes.c_uint8 * 132),
+                    ("desc_len", ctypes.c_uint32), ("table_log", ctypes.c_uint32), ("ok", ctypes.c_uint32),
+                    ("pad", ctypes.c_uint32)]
+    m.zsm_table.argtypes = [ctypes.c_void_p, ctypes.POINTER(T)]
+    rng = np.random.default_rng(3)
+    for trial in range(300):
+        k = int(rng.integers(2, 257))
+        cnt = np.zeros(256, dtype=np.uint32)
+        syms = rng.choice(256, k, replace=False)
+        kind = trial % 4
+        if kind == 0:
+            cnt[syms] = rng.integers(1, 1000, k)
+        elif kind == 1:
+            cnt[syms] = np.maximum(1, (1e6 * rng.random(k) ** 8).astype(np.uint32))   # steep
+        elif kind == 2:
+            cnt[syms] = 1 + (np.arange(k) == 0) * 10 ** 6                              # one giant
+        else:
+            fib = [1, 1]
+            while len(fib) < k:
+                fib.append(min(fib[-1] + fib[-2], 2 ** 31 // 300))
+            cnt[syms] = fib[:k]                                                       # deepest possible tree
+        t = T()
+        m.zsm_table(cnt.ctypes.data, ctypes.byref(t))
+        ln = np.array(list(t.len), dtype=np.int64)
+        if not t.ok:
+            # only a flat 256-byte alphabet has no description (and does not shrink anyway)
+            assert k > 128 and len(set(ln[ln > 0])) <= 1
+            continue
+        assert ((ln > 0) == (cnt > 0)).all() and ln.max() <= 11 and ln.max() == t.table_log
+        assert sum(2.0 ** -l for l in ln if l) == 1.0
+        codes = sorted((int(ln[s]), int(t.code[s])) for s in range(256) if ln[s])
+        seen = set()
+        for l, c in codes:  # prefix free
+            assert c < (1 << l)
+            for p in range(1, l):
+                assert (p, c >> (l - p)) not in seen
+            seen.add((l, c))
+
+
+# ------------------------------------------------------------------ GPU
+
+gpu = pytest.mark.gpu
+
+
+@gpu
+def test_device_frames_match_the_model_and_decode(model):
+    from honours_amd import press
+    z = _zstd()
+    oracle = _libs.oracle()
+    reads = cases()
+    frames = press.press_batch_host("zstd_svb_zd", reads)
+    for k, (s, f) in enumerate(zip(reads, frames)):
+        assert f is not None, "case %d" % k
+        buf = prezstd(oracle, s)
+        assert zstd_decode(z, f, len(buf)) == buf, "case %d (n=%d): libzstd" % (k, len(s))
+        assert f == model(buf), "case %d (n=%d): not the model's bytes" % (k, len(s))
+        if len(buf) > 2 * len(s):
+            continue  # press.c:1896: the reference's decoder sizes its buffer for 2 bytes per sample (+ zstd's margin)
+        ret, back = oracle.depress("zstd_svb_zd", f, s.size)   # the oracle's decoder (libzstd + svb-zd)
+        assert ret == 0 and np.array_equal(back, s)
+        if _libs.have_reference():
+            ret, back = _libs.reference().depress("zstd_svb_zd", f, s.size)
+            assert ret == 0 and np.array_equal(back, s)
+
+
+@gpu
+def test_device_frames_small_slots():
+    """a slot that is too small fails that read only"""
+    from honours_amd import press
+    rng = np.random.default_rng(5)
+    reads = [rng.integers(300, 700, 50000).astype(np.int16) for _ in range(3)]
+    full = press.press_batch_host("zstd_svb_zd", reads)
+    caps = [len(full[0]) + 64, len(full[1]) - 32, len(full[2]) + 64]  # slots are rounded up to 16 bytes
+    got = press.press_batch_host("zstd_svb_zd", reads, caps=caps)
+    assert got[0] == full[0] and got[1] is None and got[2] == full[2]
