@@ -82,7 +82,7 @@ struct Ctx {
 	bool use_user = false;
 	// scratch shared by both modes
 	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, hgran, cbits;
-	DevBuf ztmp, zoff, zoff4, zlen, zhist, ztab, zfirst, zblk, zsbits, zbpos, zbflag, zkcnt, zkbase, zrd, znb; // zstd frames
+	DevBuf ztmp, zoff, zoff4, zlen, zhist, ztab, zfirst, zblk, zsbits, zbpos, zbflag, zkcnt, zkbase, zrd, znb, zn, zdcopy, zdhuf, zdunit, zdtree, zdctl; // zstd frames
 	int use_v1 = -1; // PRESS_HIP_V1=1 selects the one-workgroup-per-read svb kernels (A/B)
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn;
@@ -120,25 +120,25 @@ struct Zstd {
 	size_t (*decompress)(void *, size_t, const void *, size_t) = nullptr;
 	size_t (*bound)(size_t) = nullptr;
 	unsigned (*is_error)(size_t) = nullptr;
-} zs;
+} zstd_fn;
 
 bool zstd_open()
 {
-	if (zs.tried)
-		return zs.compress != nullptr;
-	zs.tried = true;
+	if (zstd_fn.tried)
+		return zstd_fn.compress != nullptr;
+	zstd_fn.tried = true;
 	const char *names[] = { "/opt/conda/lib/libzstd.so.1", "libzstd.so.1", "libzstd.so", nullptr };
 	for (int i = 0; names[i]; i++) {
 		void *h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
 		if (!h)
 			continue;
-		zs.compress = (decltype(zs.compress)) dlsym(h, "ZSTD_compress");
-		zs.decompress = (decltype(zs.decompress)) dlsym(h, "ZSTD_decompress");
-		zs.bound = (decltype(zs.bound)) dlsym(h, "ZSTD_compressBound");
-		zs.is_error = (decltype(zs.is_error)) dlsym(h, "ZSTD_isError");
-		if (zs.compress && zs.decompress && zs.bound && zs.is_error)
+		zstd_fn.compress = (decltype(zstd_fn.compress)) dlsym(h, "ZSTD_compress");
+		zstd_fn.decompress = (decltype(zstd_fn.decompress)) dlsym(h, "ZSTD_decompress");
+		zstd_fn.bound = (decltype(zstd_fn.bound)) dlsym(h, "ZSTD_compressBound");
+		zstd_fn.is_error = (decltype(zstd_fn.is_error)) dlsym(h, "ZSTD_isError");
+		if (zstd_fn.compress && zstd_fn.decompress && zstd_fn.bound && zstd_fn.is_error)
 			return true;
-		zs.compress = nullptr;
+		zstd_fn.compress = nullptr;
 	}
 	return false;
 }
@@ -146,7 +146,7 @@ bool zstd_open()
 uint64_t zstd_bound_(uint64_t n)
 {
 	if (zstd_open())
-		return zs.bound(n);
+		return zstd_fn.bound(n);
 	// zstd.h ZSTD_COMPRESSBOUND
 	return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0);
 }
@@ -340,13 +340,35 @@ void zs_bufs(ZsBufs &z, uint64_t total_samples, uint32_t nreads)
 	z.rd = (ZsRead *) g.zrd.p;
 	z.nblocks = (uint32_t *) g.znb.p;
 	z.max_blocks = max_zblocks_of(total_samples, nreads);
+	z.dcopy = (ZsCopy *) g.zdcopy.p;
+	z.dhuf = (ZsHuf *) g.zdhuf.p;
+	z.dunit = (ZsUnit *) g.zdunit.p;
+	z.dtree = (ZsTree *) g.zdtree.p;
+	z.dctl = (ZsDCtl *) g.zdctl.p;
+	z.zn = (uint32_t *) g.zn.p;
+	// what a batch of this library's frames needs, with room for others; a frame that does not
+	// fit (tiny blocks, thousands of trees) goes to libzstd on the host
+	z.cap_copy = z.max_blocks + (uint32_t) (total_samples / 256) + 16 * nreads + 64;
+	z.cap_units = z.max_blocks / 16 + 2 * nreads + 64;
+	z.cap_trees = 4 * nreads + 64;
 }
 
 int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool decode)
 {
 	if (g.meta.reserve(((size_t) nreads + 1) * sizeof(ReadMeta)))
 		return PRESS_HIP_EHIP;
-	if (is_zs(method)) {
+	if (is_zs(method) && decode) {
+		ZsBufs z;
+		zs_bufs(z, total_samples, nreads);
+		const size_t nr = (size_t) nreads + 1;
+		if (g.ztmp.reserve(total_samples * 9 / 4 + nr * 64 + 64) || g.zoff.reserve(nr * 8) || g.zoff4.reserve(nr * 8) ||
+		    g.zlen.reserve(nr * 8) || g.zrd.reserve(nr * sizeof(ZsRead)) || g.zn.reserve(nr * 4) ||
+		    g.zdcopy.reserve((size_t) z.cap_copy * sizeof(ZsCopy)) || g.zdhuf.reserve((size_t) z.cap_units * 16 * sizeof(ZsHuf)) ||
+		    g.zdunit.reserve((size_t) z.cap_units * sizeof(ZsUnit)) || g.zdtree.reserve((size_t) z.cap_trees * sizeof(ZsTree)) ||
+		    g.zdctl.reserve(64))
+			return PRESS_HIP_EHIP;
+	}
+	if (is_zs(method) && !decode) {
 		const size_t mc = max_chunks_of(total_samples, nreads), mb = max_zblocks_of(total_samples, nreads);
 		const size_t nr = (size_t) nreads + 1;
 		if (g.ztmp.reserve(total_samples * 9 / 4 + nr * 64 + 64) || g.zoff.reserve(nr * 8) || g.zoff4.reserve(nr * 8) ||
@@ -582,6 +604,46 @@ static int launch_press(int method, const BatchArgs &a, hipStream_t s)
 	return 0;
 }
 
+// Frames the device walk leaves to libzstd (sequences, dictionaries, 12-bit tables ...): their
+// content is made on the host and put where the device would have put it.  Costs one stream
+// synchronisation per batch; a batch of this library's own frames has none of them.
+static int zs_host_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t s)
+{
+	ZsDCtl c;
+	HIPCHK(hipMemcpyAsync(&c, z.dctl, sizeof c, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	if (!c.nhost || !zstd_open())
+		return 0; // without libzstd those reads fail
+	const uint32_t nr = a.nreads;
+	std::vector<ZsRead> rd(nr);
+	std::vector<uint64_t> ioff(nr), ilen(nr), zoff(nr + 1);
+	std::vector<uint32_t> caps(nr);
+	HIPCHK(hipMemcpy(rd.data(), z.rd, (size_t) nr * sizeof(ZsRead), hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(ioff.data(), a.in_off, (size_t) nr * 8, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(ilen.data(), a.in_len, (size_t) nr * 8, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(zoff.data(), z.zoff, ((size_t) nr + 1) * 8, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(caps.data(), a.nsamp, (size_t) nr * 4, hipMemcpyDeviceToHost));
+	std::vector<uint8_t> frame, buf;
+	for (uint32_t r = 0; r < nr; r++) {
+		if (rd[r].mode != 3)
+			continue;
+		const uint64_t cap = 4ull + (caps[r] + 3ull) / 4 + 2ull * caps[r];
+		frame.resize(ilen[r] + 8);
+		buf.resize(cap + 8);
+		HIPCHK(hipMemcpy(frame.data(), a.in + ioff[r], ilen[r], hipMemcpyDeviceToHost));
+		const size_t got = zstd_fn.decompress(buf.data(), cap, frame.data(), ilen[r]);
+		if (zstd_fn.is_error(got)) {
+			rd[r].mode = 2;
+			continue;
+		}
+		HIPCHK(hipMemcpy(z.ztmp + zoff[r], buf.data(), got, hipMemcpyHostToDevice));
+		rd[r].mode = 0;
+		rd[r].nd = (uint32_t) got;
+	}
+	HIPCHK(hipMemcpy(z.rd, rd.data(), (size_t) nr * sizeof(ZsRead), hipMemcpyHostToDevice));
+	return 0;
+}
+
 static int launch_depress(int method, const DecodeArgs &a, hipStream_t s)
 {
 	const bool v1 = use_v1();
@@ -590,6 +652,16 @@ static int launch_depress(int method, const DecodeArgs &a, hipStream_t s)
 	case PRESS_HIP_SVB12_ZD: v1 ? launch_svb_decode(a, false, true, s) : launch_svb_decode_chunked(a, false, true, s); break;
 	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_decode(a, true, true, s) : launch_svb_decode_chunked(a, true, true, s); break;
 	case PRESS_HIP_SLOW5_SVB_ZD: launch_svb_decode_chunked(a, true, true, s, true); break;
+	case PRESS_HIP_ZSTD_SVB_ZD: {
+		ZsBufs z;
+		zs_bufs(z, g.zs_total, a.nreads);
+		launch_zstd_decode_frames(a, z, s);
+		const int rc = zs_host_frames(a, z, s);
+		if (rc)
+			return rc;
+		launch_zstd_decode_streams(a, z, s);
+		break;
+	}
 	default:
 		(v1 && !is_rc(method)) ? launch_ex_decode(a, exfmt_of(method), is_shuff(method), s)
 				       : launch_ex_decode_chunked(a, exfmt_of(method), entropy_of(method), s);
@@ -717,6 +789,7 @@ extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint
 	hipStream_t s = g.stream();
 	if ((rc = reserve_scratch(method, total_samples, nreads, true)))
 		return rc;
+	g.zs_total = total_samples;
 
 	DecodeArgs a;
 	memset(&a, 0, sizeof a);
@@ -1085,8 +1158,8 @@ int zstd_press_(int inner, bool prefix_n, const int16_t *in, uint32_t n, uint8_t
 	if (press_one(inner, in, n, buf.data() + (prefix_n ? 4 : 0), cap - (prefix_n ? 4 : 0), &len))
 		return -1;
 	len += prefix_n ? 4 : 0;
-	const size_t r = zs.compress(out, *nout, buf.data(), len, 1);
-	if (zs.is_error(r))
+	const size_t r = zstd_fn.compress(out, *nout, buf.data(), len, 1);
+	if (zstd_fn.is_error(r))
 		return -1;
 	*nout = r;
 	return 0;
@@ -1098,8 +1171,8 @@ int zstd_depress_(int inner, bool prefix_n, const uint8_t *in, uint64_t nbytes, 
 		return fail(-1, "libzstd not found"), -1;
 	const uint64_t cap = zstd_bound_((uint64_t) *nout * 2); // press.c:1897
 	std::vector<uint8_t> buf(cap + 64);
-	const size_t r = zs.decompress(buf.data(), cap, in, nbytes);
-	if (zs.is_error(r))
+	const size_t r = zstd_fn.decompress(buf.data(), cap, in, nbytes);
+	if (zstd_fn.is_error(r))
 		return -1;
 	uint32_t n = 0;
 	if (prefix_n) {

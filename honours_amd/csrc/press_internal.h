@@ -152,6 +152,27 @@ struct ZsRead {               // per read
 	uint32_t dbase;       // frame offset of the first data block
 	uint32_t pad[3];
 };
+// ZsRead on the decode side: nd = content size of the frame, mode 0 ok / 2 malformed / 3 left to libzstd
+struct ZsCopy {               // content bytes [dst, dst + n) of ztmp: a copy of n bytes at src of the arena, or its byte n times
+	uint64_t src, dst;
+	uint32_t n, fill;
+};
+struct ZsHuf {                // Huffman-coded literals of one block
+	uint64_t src, dst;    // arena offset of the streams (jump table first) / ztmp offset of the literals
+	uint32_t cs, R;       // bytes of the streams, literals
+	uint32_t four;        // 4 streams (else 1)
+	uint32_t pad;
+};
+struct ZsUnit {               // up to 16 Huffman blocks of a read with one table: one wave's work
+	uint32_t read, tree, count, pad;
+};
+struct ZsTree {
+	uint8_t w[256];       // weights (RFC 8878 4.2.1.1)
+	uint32_t tl, pad[3];
+};
+struct ZsDCtl {
+	uint32_t ncopy, nunits, ntrees, nhost;
+};
 struct ZsBufs {
 	uint8_t *ztmp;        // the svb-zd streams between the two stages: [u32 n][keys][data] of read r at zoff[r]
 	uint64_t *zoff;       // [nreads + 1]
@@ -169,8 +190,20 @@ struct ZsBufs {
 	ZsRead *rd;           // [nreads]
 	uint32_t *nblocks;    // [1]
 	uint32_t max_blocks;
+	// decode: what k_zs_walk finds in the frames
+	ZsCopy *dcopy;        // [cap_copy] raw / RLE pieces
+	ZsHuf *dhuf;          // [cap_units * 16] Huffman blocks, 16 slots per unit
+	ZsUnit *dunit;        // [cap_units]
+	ZsTree *dtree;        // [cap_trees]
+	ZsDCtl *dctl;
+	uint32_t *zn;         // [nreads] sample count found in the stream
+	uint32_t cap_copy, cap_units, cap_trees;
 };
 void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s); // press_zstd.hip
+// decode in two steps: frames -> svb-zd streams in ztmp (reads the device leaves to libzstd
+// are counted in dctl->nhost and patched in by the caller), then the svb-zd decode
+void launch_zstd_decode_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t s);
+void launch_zstd_decode_streams(const DecodeArgs &a, const ZsBufs &z, hipStream_t s);
 
 // Optional timing of the dominant kernel of a batch call with HIP events recorded on the
 // launch stream (bench.py's roofline figure): launchers call these around that kernel.

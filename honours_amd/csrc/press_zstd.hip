@@ -756,4 +756,327 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 	hipLaunchKernelGGL(k_zs_rawframes, dim3(a.nreads), dim3(256), 0, s, a, z);
 }
 
+// ==================================================================== decode
+//
+// k_zs_layout -> k_zs_walk (one lane per read: zs::walk_frame checks the frame and lists its
+// pieces) -> k_zs_copy (raw / RLE pieces) + k_zs_hdecode (one lane per Huffman stream) ->
+// [the caller lets libzstd do the frames the walk left to it] -> k_zs_finish -> svb-zd decode.
+// Frames of this library never need libzstd; neither do libzstd's own as long as a frame has
+// no sequences.
+
+namespace {
+
+struct DevSink {
+	const ZsBufs &z;
+	uint64_t in_base, out_base; // arena offset of the frame, ztmp offset of the content
+	uint32_t read;
+	uint32_t cur_tree;          // index of the table in force
+	uint32_t unit, ucount;      // the unit being filled
+
+	__device__ void push_copy(uint64_t src, uint64_t dst, uint32_t n, uint32_t fill)
+	{
+		if (!n)
+			return;
+		const uint32_t i = atomicAdd(&z.dctl->ncopy, 1u);
+		if (i < z.cap_copy) {
+			ZsCopy c;
+			c.src = in_base + src;
+			c.dst = out_base + dst;
+			c.n = n;
+			c.fill = fill;
+			z.dcopy[i] = c;
+		} else {
+			overflow = true;
+		}
+	}
+	bool overflow;
+	__device__ void copy(uint64_t src, uint64_t dst, uint32_t n) { push_copy(src, dst, n, 0); }
+	__device__ void fill(uint64_t src, uint64_t dst, uint32_t n) { push_copy(src, dst, n, 1); }
+	__device__ void close_unit()
+	{
+		if (unit != 0xFFFFFFFFu) {
+			ZsUnit u;
+			u.read = read;
+			u.tree = cur_tree;
+			u.count = ucount;
+			u.pad = 0;
+			z.dunit[unit] = u;
+		}
+		unit = 0xFFFFFFFFu;
+		ucount = 0;
+	}
+	__device__ int64_t tree(const uint8_t *w, uint32_t tl)
+	{
+		close_unit();
+		const uint32_t i = atomicAdd(&z.dctl->ntrees, 1u);
+		if (i >= z.cap_trees)
+			return zs::W_HOST;
+		ZsTree *t = z.dtree + i;
+		for (int s = 0; s < 256; s++)
+			t->w[s] = w[s];
+		t->tl = tl;
+		cur_tree = i;
+		return 0;
+	}
+	__device__ int64_t huf(uint64_t src, uint32_t cs, uint64_t dst, uint32_t R, bool four)
+	{
+		if (unit == 0xFFFFFFFFu || ucount == 16) {
+			close_unit();
+			const uint32_t u = atomicAdd(&z.dctl->nunits, 1u);
+			if (u >= z.cap_units)
+				return zs::W_HOST;
+			unit = u;
+		}
+		ZsHuf h;
+		h.src = in_base + src;
+		h.dst = out_base + dst;
+		h.cs = cs;
+		h.R = R;
+		h.four = four;
+		h.pad = 0;
+		z.dhuf[(uint64_t) unit * 16 + ucount++] = h;
+		return 0;
+	}
+};
+
+__global__ __launch_bounds__(64) void k_zs_walk(DecodeArgs a, ZsBufs z)
+{
+	const uint32_t r = blockIdx.x * 64 + threadIdx.x;
+	if (r >= a.nreads)
+		return;
+	const uint32_t cap_n = a.nsamp[r];
+	const uint64_t cap = 4ull + (cap_n + 3ull) / 4 + 2ull * cap_n; // what zs_slot() leaves room for
+	DevSink sink{ z, a.in_off[r], z.zoff[r], r, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, false };
+	int64_t L = zs::walk_frame(a.in + a.in_off[r], a.in_len[r], cap, sink);
+	sink.close_unit();
+	if (L >= 0 && sink.overflow)
+		L = zs::W_HOST;
+	ZsRead rd;
+	rd.nk = rd.knz = rd.dbase = 0;
+	rd.pad[0] = rd.pad[1] = rd.pad[2] = 0;
+	rd.nd = L >= 0 ? (uint32_t) L : 0;
+	rd.mode = L >= 0 ? 0 : L == zs::W_HOST ? 3 : 2;
+	z.rd[r] = rd;
+	if (rd.mode == 3)
+		atomicAdd(&z.dctl->nhost, 1u);
+}
+
+__device__ __forceinline__ void copy_piece(const DecodeArgs &a, const ZsBufs &z, const ZsCopy c)
+{
+	uint8_t *d = z.ztmp + c.dst;
+	const uint8_t *s = a.in + c.src;
+	if (c.fill) {
+		const uint8_t v = s[0];
+		const uint32_t v4 = v * 0x01010101u;
+		// bytes up to a 16-byte boundary, 16 at a time, the rest
+		const uint32_t head = (uint32_t) ((16 - ((uintptr_t) d & 15)) & 15);
+		const uint32_t h = head < c.n ? head : c.n;
+		if (threadIdx.x < h)
+			d[threadIdx.x] = v;
+		const uint32_t mid = (c.n - h) / 16;
+		for (uint32_t k = threadIdx.x; k < mid; k += 256)
+			*reinterpret_cast<uint4 *>(d + h + 16ull * k) = make_uint4(v4, v4, v4, v4);
+		for (uint32_t k = h + 16 * mid + threadIdx.x; k < c.n; k += 256)
+			d[k] = v;
+	} else {
+		for (uint32_t k = threadIdx.x * 16; k < c.n; k += 256 * 16) {
+			if (k + 16 <= c.n) {
+				uint4 v;
+				__builtin_memcpy(&v, s + k, 16);
+				__builtin_memcpy(d + k, &v, 16);
+			} else {
+				for (uint32_t e = k; e < c.n; e++)
+					d[e] = s[e];
+			}
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_zs_copy(DecodeArgs a, ZsBufs z)
+{
+	const uint32_t total = z.dctl->ncopy < z.cap_copy ? z.dctl->ncopy : z.cap_copy;
+	for (uint32_t i = blockIdx.x; i < total; i += gridDim.x)
+		copy_piece(a, z, z.dcopy[i]);
+}
+
+// one wave per unit: the table of its tree in LDS, one lane per bit stream
+__global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
+{
+	__shared__ uint16_t dt[2048];
+	const uint32_t u = blockIdx.x;
+	const uint32_t total = z.dctl->nunits < z.cap_units ? z.dctl->nunits : z.cap_units;
+	if (u >= total)
+		return;
+	const ZsUnit un = z.dunit[u];
+	if (un.tree >= z.cap_trees || un.count == 0 || un.count > 16)
+		return;
+	const int lane = threadIdx.x;
+	const ZsTree *t = z.dtree + un.tree;
+	const uint32_t tl = t->tl;
+	// ---- table: bytes in the order of the weights (zs::huf_build_dtable), all lanes fill
+	{
+		uint32_t w4[4], rank[4];
+		for (int i = 0; i < 4; i++)
+			w4[i] = t->w[4 * lane + i];
+		uint32_t start_x[12];
+		uint32_t at = 0;
+		for (uint32_t x = 1; x <= 11; x++) {
+			uint32_t mine = 0;
+			for (int i = 0; i < 4; i++) {
+				if (w4[i] == x)
+					rank[i] = mine;
+				mine += w4[i] == x;
+			}
+			const uint32_t inc = wave_incl32(mine, lane);
+			for (int i = 0; i < 4; i++)
+				if (w4[i] == x)
+					rank[i] += inc - mine;
+			start_x[x] = at;
+			at += __shfl(inc, 63) << (x - 1);
+		}
+		uint32_t st[4], nn[4];
+		for (int i = 0; i < 4; i++) {
+			const uint32_t x = w4[i];
+			nn[i] = x ? 1u << (x - 1) : 0;
+			uint32_t base = 0;
+			for (uint32_t y = 1; y <= 11; y++)
+				base = x == y ? start_x[y] : base;
+			st[i] = base + rank[i] * nn[i];
+		}
+		if (at != (1u << tl) || tl > 11) // cannot happen: read_tree checked the weights
+			return;
+		for (int sl = 0; sl < 64; sl++)
+			for (int i = 0; i < 4; i++) {
+				const uint32_t s0 = __shfl(st[i], sl), n0 = __shfl(nn[i], sl), x0 = __shfl(w4[i], sl);
+				const uint32_t e = (uint32_t) (4 * sl + i) | ((tl + 1 - x0) << 8);
+				for (uint32_t k = lane; k < n0; k += 64)
+					dt[s0 + k] = (uint16_t) e;
+			}
+	}
+	__syncthreads();
+	const uint32_t bi = lane >> 2, q = lane & 3;
+	bool ok = true;
+	if (bi < un.count) {
+		const ZsHuf h = z.dhuf[(uint64_t) u * 16 + bi];
+		const uint8_t *p = a.in + h.src;
+		uint8_t *out = z.ztmp + h.dst;
+		uint32_t len = 0, k = 0;
+		bool active = true;
+		if (h.four) {
+			const uint32_t s1 = p[0] | (p[1] << 8), s2 = p[2] | (p[3] << 8), s3 = p[4] | (p[5] << 8);
+			const uint32_t seg = (h.R + 3) / 4;
+			if (6ull + s1 + s2 + s3 >= h.cs || 3 * seg > h.R) {
+				ok = false;
+				active = false;
+			} else {
+				const uint32_t sz[4] = { s1, s2, s3, h.cs - 6 - s1 - s2 - s3 };
+				p += 6;
+				for (uint32_t i = 0; i < q; i++)
+					p += sz[i];
+				len = sz[q];
+				k = q < 3 ? seg : h.R - 3 * seg;
+				out += (uint64_t) q * seg;
+			}
+		} else {
+			active = q == 0;
+			len = h.cs;
+			k = h.R;
+		}
+		if (active && (len == 0 || p[len - 1] == 0)) {
+			ok = false;
+			active = false;
+		}
+		if (active) {
+			// a 64-bit window, the next bits on top; whole dwords are fetched one step ahead
+			const uint32_t lastb = p[len - 1];
+			const int hb = 31 - __builtin_clz(lastb);
+			uint64_t win = hb ? (uint64_t) (lastb & ((1u << hb) - 1)) << (64 - hb) : 0;
+			int have = hb;
+			int64_t nx = (int64_t) len - 2; // next byte to take, going down
+			uint32_t pre = 0;
+			if (nx >= 3)
+				__builtin_memcpy(&pre, p + nx - 3, 4);
+			uint32_t acc = 0;
+			for (uint32_t i = 0; i < k; i++) {
+				if (have <= 32) {
+					if (nx >= 3) {
+						win |= (uint64_t) pre << (32 - have);
+						have += 32;
+						nx -= 4;
+						if (nx >= 3)
+							__builtin_memcpy(&pre, p + nx - 3, 4);
+					} else {
+						while (have <= 56 && nx >= 0) {
+							win |= (uint64_t) p[nx] << (56 - have);
+							have += 8;
+							nx--;
+						}
+					}
+				}
+				const uint32_t e = dt[(uint32_t) (win >> (64 - tl))];
+				const uint32_t nb = e >> 8;
+				win <<= nb;
+				have -= (int) nb;
+				acc |= (e & 0xFFu) << (8 * (i & 3));
+				if ((i & 3) == 3) {
+					__builtin_memcpy(out + i - 3, &acc, 4);
+					acc = 0;
+				}
+			}
+			for (uint32_t e = k & ~3u; e < k; e++)
+				out[e] = (uint8_t) (acc >> (8 * (e & 3)));
+			ok = have == 0 && nx < 0; // the stream ends exactly here
+		}
+	}
+	if (__any(!ok) && lane == 0)
+		z.rd[un.read].mode = 2;
+}
+
+__global__ __launch_bounds__(256) void k_zs_finish(DecodeArgs a, ZsBufs z)
+{
+	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	if (r >= a.nreads)
+		return;
+	const ZsRead rd = z.rd[r];
+	const uint32_t cap_n = a.nsamp[r];
+	uint32_t n = cap_n ? cap_n : 1;
+	uint64_t len = 0; // too short for any read: the svb-zd decode reports the failure
+	if (rd.mode == 0 && rd.nd >= 4) {
+		const uint8_t *S = z.ztmp + z.zoff[r];
+		const uint32_t cnt = (uint32_t) S[0] | ((uint32_t) S[1] << 8) | ((uint32_t) S[2] << 16) | ((uint32_t) S[3] << 24);
+		if (cnt <= cap_n) { // press.c:1901: the count in the stream is what gets decoded
+			n = cnt;
+			len = rd.nd - 4;
+		}
+	}
+	z.zn[r] = n;
+	z.zlen[r] = len;
+}
+
+} // namespace
+
+void launch_zstd_decode_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t s)
+{
+	if (!a.nreads)
+		return;
+	(void) hipMemsetAsync(z.dctl, 0, sizeof(ZsDCtl), s);
+	hipLaunchKernelGGL(k_zs_layout, dim3(1), dim3(1024), 0, s, a.nsamp, a.nreads, z.zoff, z.zoff4);
+	hipLaunchKernelGGL(k_zs_walk, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a, z);
+	hipLaunchKernelGGL(k_zs_copy, dim3(z.cap_copy < 8192 ? z.cap_copy : 8192), dim3(256), 0, s, a, z);
+	hipLaunchKernelGGL(k_zs_hdecode, dim3(z.cap_units), dim3(64), 0, s, a, z);
+}
+
+void launch_zstd_decode_streams(const DecodeArgs &a, const ZsBufs &z, hipStream_t s)
+{
+	if (!a.nreads)
+		return;
+	hipLaunchKernelGGL(k_zs_finish, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a, z);
+	DecodeArgs sv = a; // the svb-zd streams are in ztmp, behind their counts
+	sv.in = z.ztmp;
+	sv.in_off = z.zoff4;
+	sv.in_len = z.zlen;
+	sv.nsamp = z.zn;
+	launch_svb_decode_chunked(sv, true, true, s);
+}
+
 } // namespace ph

@@ -362,3 +362,390 @@ ZS_FN void build_table(const uint32_t *cnt, const uint8_t *order, uint32_t m, Ta
 }
 
 } // namespace zs
+
+// ====================================================================================
+// The reading side: tree descriptions and frames (RFC 8878 3.1, 4.2.1).  Host/device code again:
+// the device walks a frame with one lane per read (press_zstd.hip), the tests walk frames on
+// the host (oracle/zsframe_model.cpp).
+namespace zs {
+
+// ---- forward little-endian bit reader (FSE table description); zeros behind the end
+struct FwdBits {
+	const uint8_t *p;
+	uint32_t len, pos;
+};
+ZS_FN uint32_t fwd_peek(const FwdBits &b, uint32_t n)
+{
+	uint32_t v = 0;
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t q = b.pos + i;
+		if ((q >> 3) < b.len && ((b.p[q >> 3] >> (q & 7u)) & 1u))
+			v |= 1u << i;
+	}
+	return v;
+}
+
+// ---- backward bit reader (FSE and Huffman streams): the last byte holds the end mark
+struct BackBits {
+	const uint8_t *p;
+	int64_t pos; // bits left below the mark; negative: read past the start
+};
+ZS_FN bool back_init(BackBits &b, const uint8_t *p, uint32_t len)
+{
+	if (!len || !p[len - 1])
+		return false;
+	b.p = p;
+	b.pos = 8ll * (len - 1) + highbit(p[len - 1]);
+	return true;
+}
+ZS_FN uint32_t back_read(BackBits &b, uint32_t n) // the n bits below pos, the highest first
+{
+	uint32_t v = 0;
+	for (uint32_t i = 0; i < n; i++) {
+		const int64_t q = b.pos - 1 - i;
+		v <<= 1;
+		if (q >= 0 && ((b.p[q >> 3] >> (q & 7)) & 1u))
+			v |= 1u;
+	}
+	b.pos -= n;
+	return v;
+}
+
+// FSE-compressed weights (FSE_decompress with table log <= 6) -> w[0..count); 0: malformed
+ZS_FN uint32_t fse_read_weights(const uint8_t *src, uint32_t len, uint8_t *w, uint32_t max_out)
+{
+	FwdBits f{ src, len, 0 };
+	const uint32_t tl = fwd_peek(f, 4) + 5;
+	f.pos += 4;
+	if (tl > 6)
+		return 0;
+	const int ts = 1 << tl;
+	int norm[16];
+	int remaining = ts + 1, threshold = ts, nbits = (int) tl + 1;
+	uint32_t charnum = 0;
+	bool prev0 = false;
+	while (remaining > 1 && charnum < 16) {
+		if (prev0) {
+			uint32_t n0 = charnum;
+			while (fwd_peek(f, 16) == 0xFFFFu) {
+				n0 += 24;
+				f.pos += 16;
+				if (f.pos > 8 * len)
+					return 0;
+			}
+			while (fwd_peek(f, 2) == 3) {
+				n0 += 3;
+				f.pos += 2;
+				if (f.pos > 8 * len)
+					return 0;
+			}
+			n0 += fwd_peek(f, 2);
+			f.pos += 2;
+			if (n0 >= 16)
+				return 0;
+			while (charnum < n0)
+				norm[charnum++] = 0;
+		}
+		const int max = (2 * threshold - 1) - remaining;
+		const int pk = (int) fwd_peek(f, (uint32_t) nbits);
+		int count;
+		if ((pk & (threshold - 1)) < max) {
+			count = pk & (threshold - 1);
+			f.pos += (uint32_t) nbits - 1;
+		} else {
+			count = pk & (2 * threshold - 1);
+			if (count >= threshold)
+				count -= max;
+			f.pos += (uint32_t) nbits;
+		}
+		count--;
+		remaining -= count < 0 ? -count : count;
+		norm[charnum++] = count;
+		prev0 = count == 0;
+		while (remaining < threshold) {
+			nbits--;
+			threshold >>= 1;
+		}
+	}
+	if (remaining != 1 || f.pos > 8 * len)
+		return 0;
+	const uint32_t hbytes = (f.pos + 7) / 8;
+	// ---- decoding table (FSE_buildDTable)
+	uint8_t dsym[64], dnb[64];
+	uint16_t dnew[64], next[16];
+	int high = ts - 1;
+	for (uint32_t s = 0; s < charnum; s++) {
+		if (norm[s] == -1) {
+			dsym[high--] = (uint8_t) s;
+			next[s] = 1;
+		} else {
+			next[s] = (uint16_t) norm[s];
+		}
+	}
+	{
+		const int step = (ts >> 1) + (ts >> 3) + 3, mask = ts - 1;
+		int pos = 0;
+		for (uint32_t s = 0; s < charnum; s++)
+			for (int i = 0; i < norm[s]; i++) {
+				dsym[pos] = (uint8_t) s;
+				pos = (pos + step) & mask;
+				while (pos > high)
+					pos = (pos + step) & mask;
+			}
+		if (pos != 0)
+			return 0;
+	}
+	for (int u = 0; u < ts; u++) {
+		const uint32_t s = dsym[u];
+		const uint32_t nx = next[s]++;
+		const uint32_t nb = tl - highbit(nx);
+		dnb[u] = (uint8_t) nb;
+		dnew[u] = (uint16_t) ((nx << nb) - (uint32_t) ts);
+	}
+	// ---- two interleaved states; whoever reads past the start ends it, the other adds its symbol
+	BackBits b;
+	if (len <= hbytes || !back_init(b, src + hbytes, len - hbytes))
+		return 0;
+	uint32_t st[2];
+	st[0] = back_read(b, tl);
+	st[1] = back_read(b, tl);
+	if (b.pos < 0)
+		return 0;
+	uint32_t out = 0;
+	for (int q = 0;; q ^= 1) {
+		if (out + 2 > max_out)
+			return 0;
+		w[out++] = dsym[st[q]];
+		st[q] = dnew[st[q]] + back_read(b, dnb[st[q]]);
+		if (b.pos < 0) {
+			w[out++] = dsym[st[q ^ 1]];
+			break;
+		}
+	}
+	return out;
+}
+
+// tree description at p -> weights of all 256 bytes, the table log; returns the bytes used,
+// 0: malformed, 0xFFFFFFFF: valid but beyond what the device decoder holds (table log 12)
+ZS_FN uint32_t read_tree(const uint8_t *p, uint32_t avail, uint8_t *w, uint32_t *table_log)
+{
+	if (!avail)
+		return 0;
+	const uint32_t hb = p[0];
+	uint32_t n, used;
+	if (hb >= 128) {
+		n = hb - 127;
+		used = 1 + (n + 1) / 2;
+		if (used > avail)
+			return 0;
+		for (uint32_t i = 0; i < n; i++)
+			w[i] = (i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4);
+	} else {
+		used = 1 + hb;
+		if (used > avail)
+			return 0;
+		n = fse_read_weights(p + 1, hb, w, 255);
+		if (!n)
+			return 0;
+	}
+	uint32_t total = 0;
+	for (uint32_t i = 0; i < n; i++) {
+		if (w[i] > 11)
+			return 0;
+		total += (1u << w[i]) >> 1;
+	}
+	if (!total)
+		return 0;
+	const uint32_t tl = highbit(total) + 1;
+	if (tl > 12)
+		return 0;
+	const uint32_t rest = (1u << tl) - total;
+	if (rest != (1u << highbit(rest)))
+		return 0;
+	w[n++] = (uint8_t) (highbit(rest) + 1);
+	uint32_t ones = 0;
+	for (uint32_t i = 0; i < n; i++)
+		ones += w[i] == 1;
+	if (ones < 2 || (ones & 1))
+		return 0;
+	for (uint32_t i = n; i < 256; i++)
+		w[i] = 0;
+	*table_log = tl;
+	return tl > (uint32_t) MAXLEN ? 0xFFFFFFFFu : used;
+}
+
+// ---- frames.  walk_frame() checks a frame and hands its pieces to a sink:
+//   sink.copy(src, dst, n)            n bytes of the frame at offset src are the content at dst
+//   sink.fill(src, dst, n)            the byte at src, n times
+//   sink.tree(w, tl) -> 0 / W_*       the Huffman table from here on: weights of the 256 bytes, table log
+//   sink.huf(src, csize, dst, R, four) -> 0 / W_*   Huffman-coded literals: csize bytes at src (jump table first
+//                                     when `four`) are R bytes at dst
+// Returns the content size, or W_BAD (malformed) / W_HOST (valid zstd this reader leaves to
+// libzstd: sequences, dictionaries, 12-bit tables, several frames).
+constexpr int64_t W_BAD = -1, W_HOST = -2;
+
+template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *f, uint64_t len, uint64_t cap, Sink &sink)
+{
+	if (len < 6 || f[0] != 0x28 || f[1] != 0xB5 || f[2] != 0x2F || f[3] != 0xFD)
+		return W_BAD;
+	const uint32_t fhd = f[4];
+	if (fhd & 8)
+		return W_BAD;
+	if (fhd & 3)
+		return W_HOST; // a dictionary
+	const bool single = fhd & 0x20, checksum = fhd & 4;
+	uint64_t at = 5;
+	if (!single)
+		at++; // the window descriptor says nothing a one-pass reader needs
+	const uint32_t fcs_flag = fhd >> 6;
+	const uint32_t fcs_bytes = fcs_flag == 0 ? (single ? 1 : 0) : fcs_flag == 1 ? 2 : fcs_flag == 2 ? 4 : 8;
+	if (at + fcs_bytes > len)
+		return W_BAD;
+	uint64_t fcs = 0;
+	for (uint32_t i = 0; i < fcs_bytes; i++)
+		fcs |= (uint64_t) f[at + i] << (8 * i);
+	if (fcs_bytes == 2)
+		fcs += 256;
+	at += fcs_bytes;
+	uint64_t dst = 0;
+	bool have_tree = false;
+	for (;;) {
+		if (at + 3 > len)
+			return W_BAD;
+		const uint32_t h = (uint32_t) f[at] | ((uint32_t) f[at + 1] << 8) | ((uint32_t) f[at + 2] << 16);
+		at += 3;
+		const bool last = h & 1;
+		const uint32_t type = (h >> 1) & 3, bs = h >> 3;
+		if (type == 3 || bs > 131072)
+			return W_BAD;
+		if (type == 0) {
+			if (at + bs > len || dst + bs > cap)
+				return W_BAD;
+			sink.copy(at, dst, bs);
+			at += bs;
+			dst += bs;
+		} else if (type == 1) {
+			if (at + 1 > len || dst + bs > cap)
+				return W_BAD;
+			sink.fill(at, dst, bs);
+			at += 1;
+			dst += bs;
+		} else {
+			if (at + bs > len || bs < 2)
+				return W_BAD;
+			const uint64_t end = at + bs;
+			const uint32_t b0 = f[at], lt = b0 & 3, sf = (b0 >> 2) & 3;
+			uint32_t lh, R, cs = 0;
+			if (lt < 2) {
+				lh = sf == 1 ? 2 : sf == 3 ? 3 : 1;
+				if (at + lh > end)
+					return W_BAD;
+				R = lh == 1 ? b0 >> 3 : lh == 2 ? (b0 >> 4) | ((uint32_t) f[at + 1] << 4)
+							: (b0 >> 4) | ((uint32_t) f[at + 1] << 4) | ((uint32_t) f[at + 2] << 12);
+				cs = lt == 0 ? R : 1;
+			} else {
+				lh = sf < 2 ? 3 : sf == 2 ? 4 : 5;
+				if (at + lh > end)
+					return W_BAD;
+				uint64_t v = 0;
+				for (uint32_t i = 0; i < lh; i++)
+					v |= (uint64_t) f[at + i] << (8 * i);
+				const uint32_t k = sf < 2 ? 10 : sf == 2 ? 14 : 18;
+				R = (uint32_t) (v >> 4) & ((1u << k) - 1);
+				cs = (uint32_t) (v >> (4 + k)) & ((1u << k) - 1);
+			}
+			if (R > 131072 || dst + R > cap || at + lh + cs + 1 > end)
+				return W_BAD;
+			// what follows the literals must be "no sequences" and the end of the block
+			if (f[at + lh + cs] != 0 || at + lh + cs + 1 != end)
+				return at + lh + cs + 1 <= end ? W_HOST : W_BAD;
+			uint64_t src = at + lh;
+			if (lt == 0) {
+				sink.copy(src, dst, R);
+			} else if (lt == 1) {
+				sink.fill(src, dst, R);
+			} else {
+				if (lt == 2) {
+					uint8_t w[256];
+					uint32_t tl;
+					const uint32_t used = read_tree(f + src, cs, w, &tl);
+					if (used == 0)
+						return W_BAD;
+					if (used == 0xFFFFFFFFu)
+						return W_HOST;
+					const int64_t e = sink.tree(w, tl);
+					if (e)
+						return e;
+					src += used;
+					cs -= used;
+					have_tree = true;
+				} else if (!have_tree) {
+					return W_BAD;
+				}
+				const bool four = sf != 0;
+				if (four ? (cs < 10 || R < 4) : cs < 1)
+					return W_BAD;
+				if (R) {
+					const int64_t e = sink.huf(src, cs, dst, R, four);
+					if (e)
+						return e;
+				}
+			}
+			at = end;
+			dst += R;
+		}
+		if (last)
+			break;
+	}
+	if (checksum)
+		at += 4; // XXH64 of the content: not verified here
+	if (at > len)
+		return W_BAD;
+	if (at != len)
+		return W_HOST; // more frames behind this one
+	if (fcs_bytes && fcs != dst)
+		return W_BAD;
+	return (int64_t) dst;
+}
+
+// one Huffman stream of a block: k bytes from the len bytes at s; dt[i] = byte | bits << 8
+// for the tl-bit prefix i.  false: the stream does not end where it must.
+ZS_FN bool huf_decode_stream(const uint8_t *s, uint32_t len, const uint16_t *dt, uint32_t tl, uint8_t *out, uint32_t k)
+{
+	BackBits b;
+	if (!back_init(b, s, len))
+		return false;
+	for (uint32_t i = 0; i < k; i++) {
+		BackBits pk = b;
+		const uint32_t e = dt[back_read(pk, tl)];
+		out[i] = (uint8_t) e;
+		b.pos -= e >> 8;
+	}
+	return b.pos == 0;
+}
+
+// decoding table from the weights (HUF_readDTableX1's order): dt[0 .. 1 << tl)
+ZS_FN void huf_build_dtable(const uint8_t *w, uint32_t tl, uint16_t *dt)
+{
+	uint32_t start[13], cnt[13];
+	for (int i = 0; i < 13; i++)
+		cnt[i] = 0;
+	for (int s = 0; s < 256; s++)
+		cnt[w[s]]++;
+	uint32_t at = 0;
+	for (uint32_t x = 1; x <= tl; x++) {
+		start[x] = at;
+		at += cnt[x] << (x - 1);
+	}
+	for (int s = 0; s < 256; s++) {
+		const uint32_t x = w[s];
+		if (!x)
+			continue;
+		const uint32_t n = 1u << (x - 1), e = (uint32_t) s | ((tl + 1 - x) << 8);
+		for (uint32_t i = 0; i < n; i++)
+			dt[start[x] + i] = (uint16_t) e;
+		start[x] += n;
+	}
+}
+
+} // namespace zs

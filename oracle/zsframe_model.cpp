@@ -192,4 +192,50 @@ uint64_t zsm_frame(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap)
 	return o.pos;
 }
 
+// the reading side on the host: walk_frame (the product's) with a sink that decodes at once.
+// Returns the content size, -1 malformed, -2 left to libzstd.
+struct HostSink {
+	const uint8_t *f;
+	uint8_t *out;
+	uint16_t dt[4096];
+	uint32_t tl;
+	void copy(uint64_t src, uint64_t dst, uint32_t n) { memcpy(out + dst, f + src, n); }
+	void fill(uint64_t src, uint64_t dst, uint32_t n) { memset(out + dst, f[src], n); }
+	int64_t tree(const uint8_t *w, uint32_t t)
+	{
+		tl = t;
+		zs::huf_build_dtable(w, t, dt);
+		return 0;
+	}
+	int64_t huf(uint64_t src, uint32_t cs, uint64_t dst, uint32_t R, bool four)
+	{
+		const uint8_t *p = f + src;
+		if (!four)
+			return zs::huf_decode_stream(p, cs, dt, tl, out + dst, R) ? 0 : zs::W_BAD;
+		const uint32_t s1 = p[0] | (p[1] << 8), s2 = p[2] | (p[3] << 8), s3 = p[4] | (p[5] << 8);
+		if (6ull + s1 + s2 + s3 >= cs)
+			return zs::W_BAD;
+		const uint32_t s4 = cs - 6 - s1 - s2 - s3, seg = (R + 3) / 4;
+		if (3 * seg > R)
+			return zs::W_BAD;
+		const uint32_t sz[4] = { s1, s2, s3, s4 };
+		p += 6;
+		for (int q = 0; q < 4; q++) {
+			if (!zs::huf_decode_stream(p, sz[q], dt, tl, out + dst + q * seg, q < 3 ? seg : R - 3 * seg))
+				return zs::W_BAD;
+			p += sz[q];
+		}
+		return 0;
+	}
+};
+
+int64_t zsm_decode(const uint8_t *frame, uint64_t len, uint8_t *out, uint64_t cap)
+{
+	HostSink s;
+	s.f = frame;
+	s.out = out;
+	s.tl = 0;
+	return zs::walk_frame(frame, len, cap, s);
+}
+
 } // extern "C"

@@ -195,3 +195,100 @@ def test_device_frames_small_slots():
     caps = [len(full[0]) + 64, len(full[1]) - 32, len(full[2]) + 64]  # slots are rounded up to 16 bytes
     got = press.press_batch_host("zstd_svb_zd", reads, caps=caps)
     assert got[0] == full[0] and got[1] is None and got[2] == full[2]
+
+
+def test_model_reader_on_both_kinds_of_frames(model):
+    """zs::walk_frame on the host: this library's frames decode; libzstd's own decode when they
+    hold no sequences and are left to libzstd (-2) otherwise - never refused, never wrong"""
+    z = _zstd()
+    oracle = _libs.oracle()
+    m = ctypes.CDLL(MODEL_SO)
+    m.zsm_decode.restype = ctypes.c_int64
+    m.zsm_decode.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+
+    def dec(f, cap):
+        a = np.frombuffer(f, dtype=np.uint8).copy()
+        out = np.zeros(cap + 64, dtype=np.uint8)
+        r = m.zsm_decode(a.ctypes.data, len(f), out.ctypes.data, cap)
+        return r, out[:max(r, 0)].tobytes()
+    own = host = 0
+    for s in cases():
+        buf = prezstd(oracle, s)
+        r, b = dec(model(buf), len(buf))
+        assert r == len(buf) and b == buf
+        a = np.frombuffer(buf, dtype=np.uint8).copy()
+        outz = np.zeros(len(buf) + len(buf) // 100 + 1024, dtype=np.uint8)
+        rz = z.ZSTD_compress(outz.ctypes.data, outz.size, a.ctypes.data, len(buf), 1)
+        r, b = dec(outz[:rz].tobytes(), len(buf))
+        assert r == -2 or (r == len(buf) and b == buf)
+        own += r >= 0
+        host += r == -2
+    assert own > 10 and host > 10  # both paths are exercised
+
+
+def _libzstd_frames(z, oracle, reads, level=1):
+    out = []
+    for s in reads:
+        buf = prezstd(oracle, s)
+        a = np.frombuffer(buf, dtype=np.uint8).copy()
+        o = np.zeros(len(buf) + len(buf) // 100 + 1024, dtype=np.uint8)
+        r = z.ZSTD_compress(o.ctypes.data, o.size, a.ctypes.data, len(buf), level)
+        out.append(o[:r].tobytes())
+    return out
+
+
+@gpu
+def test_device_reads_its_own_frames():
+    from honours_amd import press
+    reads = cases()
+    frames = press.press_batch_host("zstd_svb_zd", reads)
+    back = press.depress_batch_host("zstd_svb_zd", frames, [len(s) for s in reads])
+    for k, (s, b) in enumerate(zip(reads, back)):
+        assert b is not None and np.array_equal(b, s), "case %d (n=%d)" % (k, len(s))
+    # a larger slot than the read: the count in the stream decides (press.c:1901)
+    back = press.depress_batch_host("zstd_svb_zd", frames, [len(s) + 1000 for s in reads])
+    for s, b in zip(reads, back):
+        assert b is not None and np.array_equal(b, s)
+
+
+@gpu
+def test_device_reads_libzstd_frames():
+    """the reference's own streams (libzstd level 1, press.h:275): blocks without sequences on
+    the device, the others through libzstd on the host - same samples either way"""
+    from honours_amd import press
+    z = _zstd()
+    oracle = _libs.oracle()
+    reads = cases()
+    for level in (1, 3):
+        frames = _libzstd_frames(z, oracle, reads, level)
+        back = press.depress_batch_host("zstd_svb_zd", frames, [len(s) for s in reads])
+        for k, (s, b) in enumerate(zip(reads, back)):
+            assert b is not None and np.array_equal(b, s), "level %d case %d (n=%d)" % (level, k, len(s))
+    # and the per-read symbol of the reference's interface reads a device-made frame
+    f = press.press_batch_host("zstd_svb_zd", reads[:2])
+    for s, fr in zip(reads[:2], f):
+        ret, b = press.depress("zstd_svb_zd", fr, len(s))
+        assert ret == 0 and np.array_equal(b, s)
+
+
+@gpu
+def test_device_refuses_damaged_frames():
+    from honours_amd import press
+    rng = np.random.default_rng(9)
+    reads = [rng.integers(300, 700, 40000).astype(np.int16) for _ in range(6)]
+    good = press.press_batch_host("zstd_svb_zd", reads)
+    bad = list(good)
+    bad[1] = good[1][:len(good[1]) // 2]                      # truncated
+    bad[2] = b"\x00" + good[2][1:]                            # no magic
+    x = bytearray(good[3])
+    x[len(x) // 2] ^= 0x55                                    # a flipped byte inside a Huffman stream
+    bad[3] = bytes(x)
+    bad[4] = good[4] + b"\x00\x00\x00"                        # trailing bytes
+    back = press.depress_batch_host("zstd_svb_zd", bad, [len(s) for s in reads])
+    assert np.array_equal(back[0], reads[0]) and np.array_equal(back[5], reads[5])
+    assert back[1] is None and back[2] is None and back[4] is None
+    # a flipped bit either breaks a stream's end (refused) or decodes to other samples - never the read
+    assert back[3] is None or not np.array_equal(back[3], reads[3])
+    # too small a slot for the count in the stream
+    back = press.depress_batch_host("zstd_svb_zd", good[:2], [len(reads[0]), len(reads[1]) - 1])
+    assert np.array_equal(back[0], reads[0]) and back[1] is None
