@@ -38,6 +38,7 @@ WORKLOADS = {
     "hasgam_vbsse21_zdq": "NA12878-like synthetic reads, ex-zd (hasgam_vbsse21_zdq)",
     "shuffman_vbe21_zd": "NA12878-like synthetic reads, ex split + static NA12878_zd Huffman (shuffman_vbe21_zd)",
     "slow5_svb_zd": "NA12878-like synthetic reads, BLOW5's signal codec (slow5lib svb-zd: u32 count + svb32 of zig-zag deltas)",
+    "zstd_svb_zd": "NA12878-like synthetic reads, full VBZ pipeline zstd(svb-zd) with the zstd frames made and read on the device (config 3)",
     "rc_vbe21_zd": "NA12878-like synthetic reads, ex split + order-0 adaptive range coder (rc_vbe21_zd; serial per read by format)",
 }
 
@@ -154,6 +155,7 @@ def main():
                 "svb_zd": ("k_svb_encode_chunked<true,true>", "k_svb_decode_chunked<true,true>"),
                 "slow5_svb_zd": ("k_svb_encode_chunked<true,true,true>", "k_svb_decode_chunked<true,true,true>"),
                 "rc_vbe21_zd": ("k_rcs_encode", "k_rcs_decode"),
+                "zstd_svb_zd": ("k_svb_encode_chunked<true,true>", "k_svb_decode_chunked<true,true>"),
                 "shuffman_vbe21_zd": ("k_huff_encode_chunked", "k_huff_decode_tiles")}.get(
                     m, ("k_low_encode_chunked", "k_low_decode_chunked<false>"))
         traffic = measured_traffic(m, R, args.seed, args.fixed_len)

@@ -766,35 +766,69 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 
 namespace {
 
+// Every lane of the wave runs the same walk on the same bytes (uniform control flow, no
+// divergence between reads); lane 0 writes what is found.
 struct DevSink {
 	const ZsBufs &z;
 	uint64_t in_base, out_base; // arena offset of the frame, ztmp offset of the content
 	uint32_t read;
 	uint32_t cur_tree;          // index of the table in force
 	uint32_t unit, ucount;      // the unit being filled
+	bool overflow;
 
+	uint32_t cbase, cleft;      // copy slots taken eight at a time (one atomic), unused ones are cleared
+
+	__device__ uint32_t take(uint32_t *ctr, uint32_t n = 1)
+	{
+		uint32_t i = 0;
+		if (threadIdx.x == 0)
+			i = atomicAdd(ctr, n);
+		return (uint32_t) __shfl((int) i, 0);
+	}
+	// frame bytes for the walk: the lanes share the loads
+	__device__ void fetch(uint8_t *dst, const uint8_t *src, uint32_t n)
+	{
+		for (uint32_t j = threadIdx.x; j < n; j += 64)
+			dst[j] = src[j];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+	__device__ void close_copies()
+	{
+		if (threadIdx.x == 0)
+			for (uint32_t j = 0; j < cleft; j++)
+				if (cbase + j < z.cap_copy)
+					z.dcopy[cbase + j].n = 0;
+		cleft = 0;
+	}
 	__device__ void push_copy(uint64_t src, uint64_t dst, uint32_t n, uint32_t fill)
 	{
 		if (!n)
 			return;
-		const uint32_t i = atomicAdd(&z.dctl->ncopy, 1u);
+		if (!cleft) {
+			cbase = take(&z.dctl->ncopy, 8);
+			cleft = 8;
+		}
+		const uint32_t i = cbase++;
+		cleft--;
 		if (i < z.cap_copy) {
 			ZsCopy c;
 			c.src = in_base + src;
 			c.dst = out_base + dst;
 			c.n = n;
 			c.fill = fill;
-			z.dcopy[i] = c;
+			if (threadIdx.x == 0)
+				z.dcopy[i] = c;
 		} else {
 			overflow = true;
 		}
 	}
-	bool overflow;
 	__device__ void copy(uint64_t src, uint64_t dst, uint32_t n) { push_copy(src, dst, n, 0); }
 	__device__ void fill(uint64_t src, uint64_t dst, uint32_t n) { push_copy(src, dst, n, 1); }
 	__device__ void close_unit()
 	{
-		if (unit != 0xFFFFFFFFu) {
+		if (unit != 0xFFFFFFFFu && threadIdx.x == 0) {
 			ZsUnit u;
 			u.read = read;
 			u.tree = cur_tree;
@@ -808,13 +842,14 @@ struct DevSink {
 	__device__ int64_t tree(const uint8_t *w, uint32_t tl)
 	{
 		close_unit();
-		const uint32_t i = atomicAdd(&z.dctl->ntrees, 1u);
+		const uint32_t i = take(&z.dctl->ntrees);
 		if (i >= z.cap_trees)
 			return zs::W_HOST;
 		ZsTree *t = z.dtree + i;
-		for (int s = 0; s < 256; s++)
+		for (int s = threadIdx.x; s < 256; s += 64)
 			t->w[s] = w[s];
-		t->tl = tl;
+		if (threadIdx.x == 0)
+			t->tl = tl;
 		cur_tree = i;
 		return 0;
 	}
@@ -822,7 +857,7 @@ struct DevSink {
 	{
 		if (unit == 0xFFFFFFFFu || ucount == 16) {
 			close_unit();
-			const uint32_t u = atomicAdd(&z.dctl->nunits, 1u);
+			const uint32_t u = take(&z.dctl->nunits);
 			if (u >= z.cap_units)
 				return zs::W_HOST;
 			unit = u;
@@ -834,23 +869,27 @@ struct DevSink {
 		h.R = R;
 		h.four = four;
 		h.pad = 0;
-		z.dhuf[(uint64_t) unit * 16 + ucount++] = h;
+		if (threadIdx.x == 0)
+			z.dhuf[(uint64_t) unit * 16 + ucount] = h;
+		ucount++;
 		return 0;
 	}
 };
 
 __global__ __launch_bounds__(64) void k_zs_walk(DecodeArgs a, ZsBufs z)
 {
-	const uint32_t r = blockIdx.x * 64 + threadIdx.x;
-	if (r >= a.nreads)
-		return;
+	__shared__ zs::ReadWork work;
+	const uint32_t r = blockIdx.x;
 	const uint32_t cap_n = a.nsamp[r];
 	const uint64_t cap = 4ull + (cap_n + 3ull) / 4 + 2ull * cap_n; // what zs_slot() leaves room for
-	DevSink sink{ z, a.in_off[r], z.zoff[r], r, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, false };
-	int64_t L = zs::walk_frame(a.in + a.in_off[r], a.in_len[r], cap, sink);
+	DevSink sink{ z, a.in_off[r], z.zoff[r], r, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, false, 0, 0 };
+	int64_t L = zs::walk_frame(a.in + a.in_off[r], a.in_len[r], cap, sink, work);
 	sink.close_unit();
+	sink.close_copies();
 	if (L >= 0 && sink.overflow)
 		L = zs::W_HOST;
+	if (threadIdx.x)
+		return;
 	ZsRead rd;
 	rd.nk = rd.knz = rd.dbase = 0;
 	rd.pad[0] = rd.pad[1] = rd.pad[2] = 0;
@@ -863,6 +902,8 @@ __global__ __launch_bounds__(64) void k_zs_walk(DecodeArgs a, ZsBufs z)
 
 __device__ __forceinline__ void copy_piece(const DecodeArgs &a, const ZsBufs &z, const ZsCopy c)
 {
+	if (!c.n)
+		return;
 	uint8_t *d = z.ztmp + c.dst;
 	const uint8_t *s = a.in + c.src;
 	if (c.fill) {
@@ -899,10 +940,14 @@ __global__ __launch_bounds__(256) void k_zs_copy(DecodeArgs a, ZsBufs z)
 		copy_piece(a, z, z.dcopy[i]);
 }
 
+constexpr uint32_t HD_SYMS = 64; // bytes decoded per round
+constexpr uint32_t HD_IN = 96;   // stream bytes staged per round: 64 codes of at most 11 bits + the window's refill
 // one wave per unit: the table of its tree in LDS, one lane per bit stream
 __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 {
 	__shared__ uint16_t dt[2048];
+	__shared__ uint32_t sin[64][HD_IN / 4 + 1];   // odd stride: a lane's slot starts in its own bank (+1: word_at reads a pair)
+	__shared__ uint32_t sout[64][HD_SYMS / 4 + 1];
 	const uint32_t u = blockIdx.x;
 	const uint32_t total = z.dctl->nunits < z.cap_units ? z.dctl->nunits : z.cap_units;
 	if (u >= total)
@@ -956,12 +1001,19 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	__syncthreads();
 	const uint32_t bi = lane >> 2, q = lane & 3;
 	bool ok = true;
+	// ---- one lane per stream.  Global memory is touched in bulk only: per round of HD_SYMS
+	// bytes a lane copies the HD_IN stream bytes below its position into its LDS slot, decodes
+	// from there into its output slot and stores that slot (a load per refill and a store per
+	// four bytes would wait on each other: loads and stores share one counter on this part).
+	const uint8_t *p = nullptr;
+	uint8_t *out = nullptr;
+	uint32_t len = 0, k = 0;
+	bool active = false;
 	if (bi < un.count) {
 		const ZsHuf h = z.dhuf[(uint64_t) u * 16 + bi];
-		const uint8_t *p = a.in + h.src;
-		uint8_t *out = z.ztmp + h.dst;
-		uint32_t len = 0, k = 0;
-		bool active = true;
+		p = a.in + h.src;
+		out = z.ztmp + h.dst;
+		active = true;
 		if (h.four) {
 			const uint32_t s1 = p[0] | (p[1] << 8), s2 = p[2] | (p[3] << 8), s3 = p[4] | (p[5] << 8);
 			const uint32_t seg = (h.R + 3) / 4;
@@ -986,48 +1038,100 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 			ok = false;
 			active = false;
 		}
-		if (active) {
-			// a 64-bit window, the next bits on top; whole dwords are fetched one step ahead
-			const uint32_t lastb = p[len - 1];
-			const int hb = 31 - __builtin_clz(lastb);
-			uint64_t win = hb ? (uint64_t) (lastb & ((1u << hb) - 1)) << (64 - hb) : 0;
-			int have = hb;
-			int64_t nx = (int64_t) len - 2; // next byte to take, going down
-			uint32_t pre = 0;
-			if (nx >= 3)
-				__builtin_memcpy(&pre, p + nx - 3, 4);
-			uint32_t acc = 0;
-			for (uint32_t i = 0; i < k; i++) {
-				if (have <= 32) {
-					if (nx >= 3) {
-						win |= (uint64_t) pre << (32 - have);
-						have += 32;
-						nx -= 4;
-						if (nx >= 3)
-							__builtin_memcpy(&pre, p + nx - 3, 4);
-					} else {
-						while (have <= 56 && nx >= 0) {
-							win |= (uint64_t) p[nx] << (56 - have);
-							have += 8;
-							nx--;
-						}
+	}
+	uint64_t win = 0;
+	int have = 0;
+	int64_t nx = -1; // next stream byte to take, going down
+	if (active) {
+		const uint32_t lastb = p[len - 1];
+		const int hb = 31 - __builtin_clz(lastb);
+		win = hb ? (uint64_t) (lastb & ((1u << hb) - 1)) << (64 - hb) : 0;
+		have = hb;
+		nx = (int64_t) len - 2;
+	}
+	uint32_t *myin = sin[lane];
+	uint32_t *myout = sout[lane];
+	for (uint32_t done = 0; __any(active && done < k); done += HD_SYMS) {
+		const bool go = active && done < k;
+		const uint32_t cnt = go ? (k - done < HD_SYMS ? k - done : HD_SYMS) : 0;
+		// the HD_IN stream bytes up to nx: slot byte j is stream byte base + j.  All loads are
+		// issued before anything waits for one of them.
+		const int64_t base = nx > (int64_t) (HD_IN - 1) ? nx - (int64_t) (HD_IN - 1) : 0;
+		uint4 v[HD_IN / 16];
+#pragma unroll
+		for (int c = 0; c < (int) HD_IN / 16; c++) {
+			v[c] = make_uint4(0, 0, 0, 0);
+			if (go && base + 16 * c + 16 <= (int64_t) len)
+				__builtin_memcpy(&v[c], p + base + 16 * c, 16);
+		}
+#pragma unroll
+		for (int c = 0; c < (int) HD_IN / 16; c++) {
+			myin[4 * c] = v[c].x;
+			myin[4 * c + 1] = v[c].y;
+			myin[4 * c + 2] = v[c].z;
+			myin[4 * c + 3] = v[c].w;
+		}
+		if (go && base == 0 && len < HD_IN) { // a short stream: its last, partial 16 bytes one by one
+			for (uint32_t e = len & ~15u; e < len; e++) {
+				const uint32_t b = p[e];
+				myin[e >> 2] = (myin[e >> 2] & ~(0xFFu << (8 * (e & 3)))) | (b << (8 * (e & 3)));
+			}
+		}
+		uint32_t acc = 0;
+		int sl = (int) (nx - base); // slot byte of stream byte nx
+		// the next four stream bytes (slot bytes sl-3 .. sl) are read one refill ahead
+		// (the pair of dwords is only read here - it is shifted into place when it is used, so
+		// that nothing waits for it before the table lookup of this byte does)
+		uint32_t plo = myin[(sl >= 3 ? sl - 3 : 0) >> 2], phi = myin[((sl >= 3 ? sl - 3 : 0) >> 2) + 1];
+		for (uint32_t i = 0; i < cnt; i++) {
+			if (have <= 32) {
+				if (nx >= 3) {
+					const uint32_t pre = (uint32_t) ((((uint64_t) phi << 32) | plo) >> (8 * ((sl - 3) & 3)));
+					win |= (uint64_t) pre << (32 - have);
+					have += 32;
+					nx -= 4;
+					sl -= 4;
+					const int s3 = sl >= 3 ? sl - 3 : 0;
+					plo = myin[s3 >> 2];
+					phi = myin[(s3 >> 2) + 1];
+				} else {
+					while (have <= 56 && nx >= 0) {
+						const uint32_t b = (myin[sl >> 2] >> (8 * (sl & 3))) & 0xFFu;
+						win |= (uint64_t) b << (56 - have);
+						have += 8;
+						nx--;
+						sl--;
 					}
 				}
-				const uint32_t e = dt[(uint32_t) (win >> (64 - tl))];
-				const uint32_t nb = e >> 8;
-				win <<= nb;
-				have -= (int) nb;
-				acc |= (e & 0xFFu) << (8 * (i & 3));
-				if ((i & 3) == 3) {
-					__builtin_memcpy(out + i - 3, &acc, 4);
-					acc = 0;
-				}
 			}
-			for (uint32_t e = k & ~3u; e < k; e++)
-				out[e] = (uint8_t) (acc >> (8 * (e & 3)));
-			ok = have == 0 && nx < 0; // the stream ends exactly here
+			const uint32_t e = dt[(uint32_t) (win >> (64 - tl))];
+			const uint32_t nb = e >> 8;
+			win <<= nb;
+			have -= (int) nb;
+			acc |= (e & 0xFFu) << (8 * (i & 3));
+			if ((i & 3) == 3) {
+				myout[i >> 2] = acc;
+				acc = 0;
+			}
+		}
+		if (cnt & 3)
+			myout[cnt >> 2] = acc;
+		if (go) {
+			uint8_t *o = out + done;
+			if (cnt == HD_SYMS) {
+#pragma unroll
+				for (int c = 0; c < (int) HD_SYMS / 16; c++) {
+					const uint4 v = make_uint4(myout[4 * c], myout[4 * c + 1], myout[4 * c + 2], myout[4 * c + 3]);
+					__builtin_memcpy(o + 16 * c, &v, 16);
+				}
+			} else {
+				for (uint32_t e = 0; e < cnt; e++)
+					o[e] = (uint8_t) (myout[e >> 2] >> (8 * (e & 3)));
+			}
 		}
 	}
+	if (active)
+		ok = have == 0 && nx < 0; // the stream ends exactly here
 	if (__any(!ok) && lane == 0)
 		z.rd[un.read].mode = 2;
 }
@@ -1061,7 +1165,7 @@ void launch_zstd_decode_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t
 		return;
 	(void) hipMemsetAsync(z.dctl, 0, sizeof(ZsDCtl), s);
 	hipLaunchKernelGGL(k_zs_layout, dim3(1), dim3(1024), 0, s, a.nsamp, a.nreads, z.zoff, z.zoff4);
-	hipLaunchKernelGGL(k_zs_walk, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a, z);
+	hipLaunchKernelGGL(k_zs_walk, dim3(a.nreads), dim3(64), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_copy, dim3(z.cap_copy < 8192 ? z.cap_copy : 8192), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_hdecode, dim3(z.cap_units), dim3(64), 0, s, a, z);
 }

@@ -411,16 +411,29 @@ ZS_FN uint32_t back_read(BackBits &b, uint32_t n) // the n bits below pos, the h
 	return v;
 }
 
+// scratch of the reading side (LDS on the device, where every lane of a wave runs the same walk)
+constexpr uint32_t WIN = 32; // frame bytes fetched at a time by walk_frame
+struct ReadWork {
+	uint8_t win[WIN];
+	uint8_t w[256];
+	uint8_t desc[DESC_MAX + 4];
+	uint8_t dsym[64], dnb[64];
+	uint16_t dnew[64], next[16];
+	int norm[16];
+};
+
 // FSE-compressed weights (FSE_decompress with table log <= 6) -> w[0..count); 0: malformed
-ZS_FN uint32_t fse_read_weights(const uint8_t *src, uint32_t len, uint8_t *w, uint32_t max_out)
+ZS_FN uint32_t fse_read_weights(const uint8_t *src, uint32_t len, uint8_t *w, uint32_t max_out, ReadWork &k)
 {
+	int *norm = k.norm;
+	uint8_t *dsym = k.dsym, *dnb = k.dnb;
+	uint16_t *dnew = k.dnew, *next = k.next;
 	FwdBits f{ src, len, 0 };
 	const uint32_t tl = fwd_peek(f, 4) + 5;
 	f.pos += 4;
 	if (tl > 6)
 		return 0;
 	const int ts = 1 << tl;
-	int norm[16];
 	int remaining = ts + 1, threshold = ts, nbits = (int) tl + 1;
 	uint32_t charnum = 0;
 	bool prev0 = false;
@@ -471,8 +484,6 @@ ZS_FN uint32_t fse_read_weights(const uint8_t *src, uint32_t len, uint8_t *w, ui
 		return 0;
 	const uint32_t hbytes = (f.pos + 7) / 8;
 	// ---- decoding table (FSE_buildDTable)
-	uint8_t dsym[64], dnb[64];
-	uint16_t dnew[64], next[16];
 	int high = ts - 1;
 	for (uint32_t s = 0; s < charnum; s++) {
 		if (norm[s] == -1) {
@@ -527,7 +538,7 @@ ZS_FN uint32_t fse_read_weights(const uint8_t *src, uint32_t len, uint8_t *w, ui
 
 // tree description at p -> weights of all 256 bytes, the table log; returns the bytes used,
 // 0: malformed, 0xFFFFFFFF: valid but beyond what the device decoder holds (table log 12)
-ZS_FN uint32_t read_tree(const uint8_t *p, uint32_t avail, uint8_t *w, uint32_t *table_log)
+ZS_FN uint32_t read_tree(const uint8_t *p, uint32_t avail, uint8_t *w, uint32_t *table_log, ReadWork &k)
 {
 	if (!avail)
 		return 0;
@@ -544,7 +555,7 @@ ZS_FN uint32_t read_tree(const uint8_t *p, uint32_t avail, uint8_t *w, uint32_t 
 		used = 1 + hb;
 		if (used > avail)
 			return 0;
-		n = fse_read_weights(p + 1, hb, w, 255);
+		n = fse_read_weights(p + 1, hb, w, 255, k);
 		if (!n)
 			return 0;
 	}
@@ -575,6 +586,7 @@ ZS_FN uint32_t read_tree(const uint8_t *p, uint32_t avail, uint8_t *w, uint32_t 
 }
 
 // ---- frames.  walk_frame() checks a frame and hands its pieces to a sink:
+//   sink.fetch(dst, src, n)           n frame bytes for the walk itself (dst: the window / the description buffer)
 //   sink.copy(src, dst, n)            n bytes of the frame at offset src are the content at dst
 //   sink.fill(src, dst, n)            the byte at src, n times
 //   sink.tree(w, tl) -> 0 / W_*       the Huffman table from here on: weights of the 256 bytes, table log
@@ -584,8 +596,30 @@ ZS_FN uint32_t read_tree(const uint8_t *p, uint32_t avail, uint8_t *w, uint32_t 
 // libzstd: sequences, dictionaries, 12-bit tables, several frames).
 constexpr int64_t W_BAD = -1, W_HOST = -2;
 
-template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *f, uint64_t len, uint64_t cap, Sink &sink)
+// Frame bytes come through a window of WIN bytes that the sink fills (sink.fetch(dst, src, n):
+// on the device a wave's lanes share the loads).  The walk touches a few bytes per block - the
+// block header, the literals header behind it and the "no sequences" byte in front of the next
+// header - so one fetch per block is the rule.
+template <class Sink> struct FrameSrc {
+	const uint8_t *f;
+	uint64_t len, base;
+	bool valid;
+	Sink &sink;
+	ReadWork &k;
+	ZS_FN uint32_t operator[](uint64_t i) // i < len
+	{
+		if (!valid || i < base || i >= base + WIN) {
+			base = i;
+			valid = true;
+			sink.fetch(k.win, f + i, len - i < WIN ? (uint32_t) (len - i) : WIN);
+		}
+		return k.win[i - base];
+	}
+};
+
+template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, uint64_t cap, Sink &sink, ReadWork &k)
 {
+	FrameSrc<Sink> f{ fp, len, 0, false, sink, k };
 	if (len < 6 || f[0] != 0x28 || f[1] != 0xB5 || f[2] != 0x2F || f[3] != 0xFD)
 		return W_BAD;
 	const uint32_t fhd = f[4];
@@ -640,8 +674,7 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *f, uint64_t len, u
 				lh = sf == 1 ? 2 : sf == 3 ? 3 : 1;
 				if (at + lh > end)
 					return W_BAD;
-				R = lh == 1 ? b0 >> 3 : lh == 2 ? (b0 >> 4) | ((uint32_t) f[at + 1] << 4)
-							: (b0 >> 4) | ((uint32_t) f[at + 1] << 4) | ((uint32_t) f[at + 2] << 12);
+				R = lh == 1 ? b0 >> 3 : lh == 2 ? (b0 >> 4) | (f[at + 1] << 4) : (b0 >> 4) | (f[at + 1] << 4) | (f[at + 2] << 12);
 				cs = lt == 0 ? R : 1;
 			} else {
 				lh = sf < 2 ? 3 : sf == 2 ? 4 : 5;
@@ -650,15 +683,15 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *f, uint64_t len, u
 				uint64_t v = 0;
 				for (uint32_t i = 0; i < lh; i++)
 					v |= (uint64_t) f[at + i] << (8 * i);
-				const uint32_t k = sf < 2 ? 10 : sf == 2 ? 14 : 18;
-				R = (uint32_t) (v >> 4) & ((1u << k) - 1);
-				cs = (uint32_t) (v >> (4 + k)) & ((1u << k) - 1);
+				const uint32_t kb = sf < 2 ? 10 : sf == 2 ? 14 : 18;
+				R = (uint32_t) (v >> 4) & ((1u << kb) - 1);
+				cs = (uint32_t) (v >> (4 + kb)) & ((1u << kb) - 1);
 			}
 			if (R > 131072 || dst + R > cap || at + lh + cs + 1 > end)
 				return W_BAD;
 			// what follows the literals must be "no sequences" and the end of the block
 			if (f[at + lh + cs] != 0 || at + lh + cs + 1 != end)
-				return at + lh + cs + 1 <= end ? W_HOST : W_BAD;
+				return W_HOST;
 			uint64_t src = at + lh;
 			if (lt == 0) {
 				sink.copy(src, dst, R);
@@ -666,9 +699,11 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *f, uint64_t len, u
 				sink.fill(src, dst, R);
 			} else {
 				if (lt == 2) {
-					uint8_t w[256];
+					uint8_t *w = k.w;
 					uint32_t tl;
-					const uint32_t used = read_tree(f + src, cs, w, &tl);
+					const uint32_t dn = cs < (uint32_t) DESC_MAX ? cs : (uint32_t) DESC_MAX;
+					sink.fetch(k.desc, fp + src, dn);
+					const uint32_t used = read_tree(k.desc, dn, w, &tl, k);
 					if (used == 0)
 						return W_BAD;
 					if (used == 0xFFFFFFFFu)

@@ -199,6 +199,7 @@ struct HostSink {
 	uint8_t *out;
 	uint16_t dt[4096];
 	uint32_t tl;
+	void fetch(uint8_t *dst, const uint8_t *src, uint32_t n) { memcpy(dst, src, n); }
 	void copy(uint64_t src, uint64_t dst, uint32_t n) { memcpy(out + dst, f + src, n); }
 	void fill(uint64_t src, uint64_t dst, uint32_t n) { memset(out + dst, f[src], n); }
 	int64_t tree(const uint8_t *w, uint32_t t)
@@ -235,7 +236,8 @@ int64_t zsm_decode(const uint8_t *frame, uint64_t len, uint8_t *out, uint64_t ca
 	s.f = frame;
 	s.out = out;
 	s.tl = 0;
-	return zs::walk_frame(frame, len, cap, s);
+	zs::ReadWork k;
+	return zs::walk_frame(frame, len, cap, s, k);
 }
 
 } // extern "C"
