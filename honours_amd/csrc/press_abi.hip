@@ -349,7 +349,7 @@ void zs_bufs(ZsBufs &z, uint64_t total_samples, uint32_t nreads)
 	// what a batch of this library's frames needs, with room for others; a frame that does not
 	// fit (tiny blocks, thousands of trees) goes to libzstd on the host
 	z.cap_copy = z.max_blocks + (uint32_t) (total_samples / 256) + 16 * nreads + 64;
-	z.cap_units = z.max_blocks / 16 + 2 * nreads + 64;
+	z.cap_units = z.max_blocks / 8 + 2 * nreads + 64;
 	z.cap_trees = 4 * nreads + 64;
 }
 
@@ -363,7 +363,7 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 		const size_t nr = (size_t) nreads + 1;
 		if (g.ztmp.reserve(total_samples * 9 / 4 + nr * 64 + 64) || g.zoff.reserve(nr * 8) || g.zoff4.reserve(nr * 8) ||
 		    g.zlen.reserve(nr * 8) || g.zrd.reserve(nr * sizeof(ZsRead)) || g.zn.reserve(nr * 4) ||
-		    g.zdcopy.reserve((size_t) z.cap_copy * sizeof(ZsCopy)) || g.zdhuf.reserve((size_t) z.cap_units * 16 * sizeof(ZsHuf)) ||
+		    g.zdcopy.reserve((size_t) z.cap_copy * sizeof(ZsCopy)) || g.zdhuf.reserve((size_t) z.cap_units * 8 * sizeof(ZsHuf)) ||
 		    g.zdunit.reserve((size_t) z.cap_units * sizeof(ZsUnit)) || g.zdtree.reserve((size_t) z.cap_trees * sizeof(ZsTree)) ||
 		    g.zdctl.reserve(64))
 			return PRESS_HIP_EHIP;

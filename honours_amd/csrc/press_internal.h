@@ -163,7 +163,7 @@ struct ZsHuf {                // Huffman-coded literals of one block
 	uint32_t four;        // 4 streams (else 1)
 	uint32_t pad;
 };
-struct ZsUnit {               // up to 16 Huffman blocks of a read with one table: one wave's work
+struct ZsUnit {               // up to 8 Huffman blocks of a read with one table: half a wave's work
 	uint32_t read, tree, count, pad;
 };
 struct ZsTree {
@@ -192,7 +192,7 @@ struct ZsBufs {
 	uint32_t max_blocks;
 	// decode: what k_zs_walk finds in the frames
 	ZsCopy *dcopy;        // [cap_copy] raw / RLE pieces
-	ZsHuf *dhuf;          // [cap_units * 16] Huffman blocks, 16 slots per unit
+	ZsHuf *dhuf;          // [cap_units * 8] Huffman blocks, 8 slots per unit
 	ZsUnit *dunit;        // [cap_units]
 	ZsTree *dtree;        // [cap_trees]
 	ZsDCtl *dctl;

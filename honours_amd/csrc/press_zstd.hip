@@ -768,6 +768,7 @@ namespace {
 
 // Every lane of the wave runs the same walk on the same bytes (uniform control flow, no
 // divergence between reads); lane 0 writes what is found.
+constexpr uint32_t ZU = 8; // Huffman blocks per unit (32 streams: half a wave)
 struct DevSink {
 	const ZsBufs &z;
 	uint64_t in_base, out_base; // arena offset of the frame, ztmp offset of the content
@@ -855,7 +856,7 @@ struct DevSink {
 	}
 	__device__ int64_t huf(uint64_t src, uint32_t cs, uint64_t dst, uint32_t R, bool four)
 	{
-		if (unit == 0xFFFFFFFFu || ucount == 16) {
+		if (unit == 0xFFFFFFFFu || ucount == ZU) {
 			close_unit();
 			const uint32_t u = take(&z.dctl->nunits);
 			if (u >= z.cap_units)
@@ -870,7 +871,7 @@ struct DevSink {
 		h.four = four;
 		h.pad = 0;
 		if (threadIdx.x == 0)
-			z.dhuf[(uint64_t) unit * 16 + ucount] = h;
+			z.dhuf[(uint64_t) unit * ZU + ucount] = h;
 		ucount++;
 		return 0;
 	}
@@ -942,24 +943,31 @@ __global__ __launch_bounds__(256) void k_zs_copy(DecodeArgs a, ZsBufs z)
 
 constexpr uint32_t HD_SYMS = 64; // bytes decoded per round
 constexpr uint32_t HD_IN = 96;   // stream bytes staged per round: 64 codes of at most 11 bits + the window's refill
-// one wave per unit: the table of its tree in LDS, one lane per bit stream
+// one wave per PAIR of units (a unit = up to ZU blocks of one read = 32 streams; the mean read has
+// 7 blocks, so whole waves per read would leave more than half of the lanes idle - and the
+// kernel is bound by the instructions per decoded byte, not by latency): two tables in LDS,
+// one lane per bit stream
 __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 {
-	__shared__ uint16_t dt[2048];
-	__shared__ uint32_t sin[64][HD_IN / 4 + 1];   // odd stride: a lane's slot starts in its own bank (+1: word_at reads a pair)
+	__shared__ uint16_t dt2[2][2048];
+	__shared__ uint32_t sin[64][HD_IN / 4 + 1];   // odd stride: a lane's slot starts in its own bank (+1: a pair is read)
 	__shared__ uint32_t sout[64][HD_SYMS / 4 + 1];
-	const uint32_t u = blockIdx.x;
 	const uint32_t total = z.dctl->nunits < z.cap_units ? z.dctl->nunits : z.cap_units;
-	if (u >= total)
-		return;
-	const ZsUnit un = z.dunit[u];
-	if (un.tree >= z.cap_trees || un.count == 0 || un.count > 16)
+	if (2 * blockIdx.x >= total)
 		return;
 	const int lane = threadIdx.x;
-	const ZsTree *t = z.dtree + un.tree;
-	const uint32_t tl = t->tl;
-	// ---- table: bytes in the order of the weights (zs::huf_build_dtable), all lanes fill
-	{
+	uint32_t tlh[2] = { 0, 0 }, cnth[2] = { 0, 0 }, readh[2] = { 0, 0 };
+	for (int hh = 0; hh < 2; hh++) {
+		const uint32_t uu = 2 * blockIdx.x + hh;
+		if (uu >= total)
+			continue;
+		const ZsUnit un = z.dunit[uu];
+		if (un.tree >= z.cap_trees || un.count == 0 || un.count > ZU)
+			continue;
+		const ZsTree *t = z.dtree + un.tree;
+		const uint32_t tl = t->tl;
+		uint16_t *dt = dt2[hh];
+		// ---- table: bytes in the order of the weights (zs::huf_build_dtable), all lanes fill
 		uint32_t w4[4], rank[4];
 		for (int i = 0; i < 4; i++)
 			w4[i] = t->w[4 * lane + i];
@@ -989,7 +997,7 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 			st[i] = base + rank[i] * nn[i];
 		}
 		if (at != (1u << tl) || tl > 11) // cannot happen: read_tree checked the weights
-			return;
+			continue;
 		for (int sl = 0; sl < 64; sl++)
 			for (int i = 0; i < 4; i++) {
 				const uint32_t s0 = __shfl(st[i], sl), n0 = __shfl(nn[i], sl), x0 = __shfl(w4[i], sl);
@@ -997,9 +1005,19 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 				for (uint32_t k = lane; k < n0; k += 64)
 					dt[s0 + k] = (uint16_t) e;
 			}
+		tlh[hh] = tl;
+		cnth[hh] = un.count;
+		readh[hh] = un.read;
 	}
 	__syncthreads();
-	const uint32_t bi = lane >> 2, q = lane & 3;
+	const int half = lane >> 5;
+	const uint32_t u = 2 * blockIdx.x + half;
+	const uint32_t tl = half ? tlh[1] : tlh[0];
+	const uint16_t *dt = dt2[half];
+	ZsUnit un;
+	un.count = half ? cnth[1] : cnth[0];
+	un.read = half ? readh[1] : readh[0];
+	const uint32_t bi = (lane & 31) >> 2, q = lane & 3;
 	bool ok = true;
 	// ---- one lane per stream.  Global memory is touched in bulk only: per round of HD_SYMS
 	// bytes a lane copies the HD_IN stream bytes below its position into its LDS slot, decodes
@@ -1010,7 +1028,7 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	uint32_t len = 0, k = 0;
 	bool active = false;
 	if (bi < un.count) {
-		const ZsHuf h = z.dhuf[(uint64_t) u * 16 + bi];
+		const ZsHuf h = z.dhuf[(uint64_t) u * ZU + bi];
 		p = a.in + h.src;
 		out = z.ztmp + h.dst;
 		active = true;
@@ -1051,25 +1069,44 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	}
 	uint32_t *myin = sin[lane];
 	uint32_t *myout = sout[lane];
+#ifdef HD_SKIP
+	k = 0;
+#endif
 	for (uint32_t done = 0; __any(active && done < k); done += HD_SYMS) {
 		const bool go = active && done < k;
 		const uint32_t cnt = go ? (k - done < HD_SYMS ? k - done : HD_SYMS) : 0;
 		// the HD_IN stream bytes up to nx: slot byte j is stream byte base + j.  All loads are
 		// issued before anything waits for one of them.
 		const int64_t base = nx > (int64_t) (HD_IN - 1) ? nx - (int64_t) (HD_IN - 1) : 0;
-		uint4 v[HD_IN / 16];
+		// six lanes share a stream's 96 bytes (16 each): a load instruction then reads ~11 runs
+		// of 96 bytes instead of 64 scattered pieces
+		{
+			const uint64_t pb = go ? (uint64_t) (uintptr_t) (p + base) : 0;
+			const uint32_t avail = go ? (uint32_t) ((int64_t) len - base < (int64_t) HD_IN ? (int64_t) len - base : (int64_t) HD_IN) : 0;
+			uint4 v[HD_IN / 16];
+			int oo[HD_IN / 16], kk[HD_IN / 16];
 #pragma unroll
-		for (int c = 0; c < (int) HD_IN / 16; c++) {
-			v[c] = make_uint4(0, 0, 0, 0);
-			if (go && base + 16 * c + 16 <= (int64_t) len)
-				__builtin_memcpy(&v[c], p + base + 16 * c, 16);
-		}
+			for (int c = 0; c < (int) HD_IN / 16; c++) {
+				const int g = 64 * c + lane;
+				oo[c] = g / 6;
+				kk[c] = g - 6 * oo[c];
+				const uint64_t opb = ((uint64_t) (uint32_t) __shfl((int) (pb >> 32), oo[c]) << 32) | (uint32_t) __shfl((int) pb, oo[c]);
+				const uint32_t oav = (uint32_t) __shfl((int) avail, oo[c]);
+				v[c] = make_uint4(0, 0, 0, 0);
+				if (16u * kk[c] + 16u <= oav)
+					__builtin_memcpy(&v[c], (const uint8_t *) (uintptr_t) opb + 16 * kk[c], 16);
+			}
 #pragma unroll
-		for (int c = 0; c < (int) HD_IN / 16; c++) {
-			myin[4 * c] = v[c].x;
-			myin[4 * c + 1] = v[c].y;
-			myin[4 * c + 2] = v[c].z;
-			myin[4 * c + 3] = v[c].w;
+			for (int c = 0; c < (int) HD_IN / 16; c++) {
+				uint32_t *row = sin[oo[c]] + 4 * kk[c];
+				row[0] = v[c].x;
+				row[1] = v[c].y;
+				row[2] = v[c].z;
+				row[3] = v[c].w;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		}
 		if (go && base == 0 && len < HD_IN) { // a short stream: its last, partial 16 bytes one by one
 			for (uint32_t e = len & ~15u; e < len; e++) {
@@ -1079,9 +1116,8 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 		}
 		uint32_t acc = 0;
 		int sl = (int) (nx - base); // slot byte of stream byte nx
-		// the next four stream bytes (slot bytes sl-3 .. sl) are read one refill ahead
-		// (the pair of dwords is only read here - it is shifted into place when it is used, so
-		// that nothing waits for it before the table lookup of this byte does)
+		// the next four stream bytes (slot bytes sl-3 .. sl) are read one refill ahead and shifted
+		// into place when they are used
 		uint32_t plo = myin[(sl >= 3 ? sl - 3 : 0) >> 2], phi = myin[((sl >= 3 ? sl - 3 : 0) >> 2) + 1];
 		for (uint32_t i = 0; i < cnt; i++) {
 			if (have <= 32) {
@@ -1116,24 +1152,40 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 		}
 		if (cnt & 3)
 			myout[cnt >> 2] = acc;
-		if (go) {
-			uint8_t *o = out + done;
-			if (cnt == HD_SYMS) {
+		// ---- the round's bytes out: four lanes share a stream's 64 bytes, 16 each, so that a
+		// store instruction writes 16 runs of 64 bytes instead of 64 scattered dwords (which cost
+		// as much as all the decoding: measured)
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		{
+			const uint64_t optr = (uint64_t) (uintptr_t) (out + done);
 #pragma unroll
-				for (int c = 0; c < (int) HD_SYMS / 16; c++) {
-					const uint4 v = make_uint4(myout[4 * c], myout[4 * c + 1], myout[4 * c + 2], myout[4 * c + 3]);
-					__builtin_memcpy(o + 16 * c, &v, 16);
+			for (int c = 0; c < 4; c++) {
+				const int o = 16 * c + (lane >> 2), part = lane & 3;
+				const uint32_t ocnt = (uint32_t) __shfl((int) cnt, o);
+				const uint64_t op = ((uint64_t) (uint32_t) __shfl((int) (optr >> 32), o) << 32) | (uint32_t) __shfl((int) optr, o);
+				if (ocnt == HD_SYMS) {
+					const uint32_t *row = sout[o] + 4 * part;
+					const uint4 v = make_uint4(row[0], row[1], row[2], row[3]);
+					__builtin_memcpy((uint8_t *) (uintptr_t) op + 16 * part, &v, 16);
 				}
-			} else {
-				for (uint32_t e = 0; e < cnt; e++)
-					o[e] = (uint8_t) (myout[e >> 2] >> (8 * (e & 3)));
 			}
+			if (cnt && cnt < HD_SYMS) // the last, short round of a stream
+				for (uint32_t e = 0; e < cnt; e++)
+					out[done + e] = (uint8_t) (myout[e >> 2] >> (8 * (e & 3)));
 		}
+		__builtin_amdgcn_wave_barrier();
 	}
 	if (active)
 		ok = have == 0 && nx < 0; // the stream ends exactly here
-	if (__any(!ok) && lane == 0)
-		z.rd[un.read].mode = 2;
+	{
+		const unsigned long long bad = __ballot(!ok);
+		if ((bad & 0xFFFFFFFFull) && lane == 0)
+			z.rd[un.read].mode = 2;
+		if ((bad >> 32) && lane == 32)
+			z.rd[un.read].mode = 2;
+	}
 }
 
 __global__ __launch_bounds__(256) void k_zs_finish(DecodeArgs a, ZsBufs z)
@@ -1167,7 +1219,7 @@ void launch_zstd_decode_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t
 	hipLaunchKernelGGL(k_zs_layout, dim3(1), dim3(1024), 0, s, a.nsamp, a.nreads, z.zoff, z.zoff4);
 	hipLaunchKernelGGL(k_zs_walk, dim3(a.nreads), dim3(64), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_copy, dim3(z.cap_copy < 8192 ? z.cap_copy : 8192), dim3(256), 0, s, a, z);
-	hipLaunchKernelGGL(k_zs_hdecode, dim3(z.cap_units), dim3(64), 0, s, a, z);
+	hipLaunchKernelGGL(k_zs_hdecode, dim3((z.cap_units + 1) / 2), dim3(64), 0, s, a, z);
 }
 
 void launch_zstd_decode_streams(const DecodeArgs &a, const ZsBufs &z, hipStream_t s)
