@@ -155,7 +155,7 @@ def main():
                 "svb_zd": ("k_svb_encode_chunked<true,true>", "k_svb_decode_chunked<true,true>"),
                 "slow5_svb_zd": ("k_svb_encode_chunked<true,true,true>", "k_svb_decode_chunked<true,true,true>"),
                 "rc_vbe21_zd": ("k_rcs_encode", "k_rcs_decode"),
-                "zstd_svb_zd": ("k_svb_encode_chunked<true,true>", "k_svb_decode_chunked<true,true>"),
+                "zstd_svb_zd": ("k_zs_encode", "k_zs_hdecode"),
                 "shuffman_vbe21_zd": ("k_huff_encode_chunked", "k_huff_decode_tiles")}.get(
                     m, ("k_low_encode_chunked", "k_low_decode_chunked<false>"))
         traffic = measured_traffic(m, R, args.seed, args.fixed_len)

@@ -420,14 +420,16 @@ struct KTime {
 } // namespace
 
 namespace ph {
+static bool kt_muted = false;
+void ktime_mute(bool m) { kt_muted = m; }
 void ktime_begin(int which, hipStream_t s)
 {
-	if (kt.on && kt.n[which] < KT_RING)
+	if (kt.on && !kt_muted && kt.n[which] < KT_RING)
 		(void) hipEventRecord(kt.ev[which][kt.n[which]][0], s);
 }
 void ktime_end(int which, hipStream_t s)
 {
-	if (kt.on && kt.n[which] < KT_RING) {
+	if (kt.on && !kt_muted && kt.n[which] < KT_RING) {
 		(void) hipEventRecord(kt.ev[which][kt.n[which]][1], s);
 		kt.n[which]++;
 	}

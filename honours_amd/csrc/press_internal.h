@@ -209,6 +209,7 @@ void launch_zstd_decode_streams(const DecodeArgs &a, const ZsBufs &z, hipStream_
 // launch stream (bench.py's roofline figure): launchers call these around that kernel.
 void ktime_begin(int which, hipStream_t s); // which: 0 = press, 1 = depress
 void ktime_end(int which, hipStream_t s);
+void ktime_mute(bool m); // a composite launcher times its own kernel instead of the inner one's
 
 // launchers (press_kernels.hip).  All asynchronous on `s`.
 void launch_svb_encode(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s);      // v1: one workgroup per read
