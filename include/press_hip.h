@@ -167,7 +167,8 @@ enum press_hip_method {
 	PRESS_HIP_SVB12            = 0,
 	PRESS_HIP_SVB12_ZD         = 1,
 	PRESS_HIP_SVB_ZD           = 2,
-	PRESS_HIP_ZSTD_SVB_ZD      = 3,  /* per-read API only (host zstd stage) */
+	PRESS_HIP_ZSTD_SVB_ZD      = 3,  /* "VBZ".  Per-read symbols: libzstd on the host, the reference's bytes.
+	                                    Batch API: the zstd frames are made and read ON THE DEVICE (below) */
 	PRESS_HIP_ZSTD_SVB12_ZD    = 4,  /* per-read API only */
 	PRESS_HIP_VBE21_ZD         = 5,
 	PRESS_HIP_VBBE21_ZD        = 6,
@@ -244,6 +245,24 @@ int press_hip_depress_batch(int method, const uint8_t *in, const uint64_t *in_of
 			    const uint64_t *in_len, uint32_t nreads, int16_t *sig,
 			    const uint64_t *off, const uint32_t *n, uint64_t total_samples,
 			    uint32_t *out_n, int device_resident);
+
+/*
+ * PRESS_HIP_ZSTD_SVB_ZD in the two calls above (replaces the ZSTD_compress /
+ * ZSTD_decompress calls of press.c:1860-1910 for batches):
+ *   press    writes one standard zstd frame (RFC 8878) per read whose content is the buffer
+ *            the reference hands to ZSTD_compress ([u32 n][svb-zd stream]): a raw block with
+ *            the count, RLE blocks for the key bytes, Huffman-coded literal blocks of 16 KiB
+ *            (one table per read, no sequences).  Any zstd decoder reads it - the reference's
+ *            zstd_svb_zd_depress_16 included; the BYTES are not libzstd's (they never were
+ *            pinned: they depend on the libzstd version).  Size <= 9 + L + 3 * ceil(L / 128 KiB)
+ *            for a content of L bytes, well inside press_hip_bound().
+ *   depress  reads any single zstd frame of such a buffer: frames without sequences (all of
+ *            the above, and libzstd's own when it found no matches) entirely on the device;
+ *            frames with sequences, dictionaries or 12-bit Huffman tables are decompressed by
+ *            libzstd on the host inside the call (one stream synchronisation per batch, only
+ *            when such a frame is present).  n[r] is the room in samples; the count in the
+ *            stream decides (press.c:1901).  Content checksums are not verified.
+ */
 
 /* bytes of device scratch the two calls above keep for a batch of this shape (informational) */
 uint64_t press_hip_workspace_bytes(int method, uint64_t total_samples, uint32_t nreads);
