@@ -159,6 +159,16 @@ def test_table_is_a_complete_prefix_code(model):
             seen.add((l, c))
 
 
+def test_reader_survives_damaged_frames():
+    """the device's frame reader (zs_table.h) compiled for the host with AddressSanitizer + UBSan on
+    10 000 truncated / extended / bit-flipped frames: stays inside the frame and inside its output"""
+    exe = os.path.join(ROOT, "oracle", "zsframe_fuzz")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "zsfuzz"], check=True)
+    r = subprocess.run([exe, "10000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "no finding" in r.stdout
+
+
 # ------------------------------------------------------------------ GPU
 
 gpu = pytest.mark.gpu
