@@ -165,7 +165,7 @@ bool is_zstd(int m)
 	return m == PRESS_HIP_ZSTD_SVB_ZD || m == PRESS_HIP_ZSTD_SVB12_ZD || m == PRESS_HIP_ZSTD_HASGAM_ZDQ;
 }
 bool is_rc(int m) { return m == PRESS_HIP_RC_VBE21_ZD; }
-bool is_zs(int m) { return m == PRESS_HIP_ZSTD_SVB_ZD; } // zstd frames made on the device (batch API)
+bool is_zs(int m) { return m == PRESS_HIP_ZSTD_SVB_ZD || m == PRESS_HIP_ZSTD_SVB12_ZD; } // zstd frames made on the device (batch API)
 bool is_ex(int m) { return (m >= PRESS_HIP_VBE21_ZD && m <= PRESS_HIP_HASGAM_ZDQ) || is_rc(m); }
 int entropy_of(int m) { return is_shuff(m) ? 1 : is_rc(m) ? 2 : 0; }
 
@@ -322,8 +322,9 @@ uint32_t max_zblocks_of(uint64_t total_samples, uint32_t nreads)
 	return (uint32_t) (total_samples * 2 / zs::BLOCK_LITS + nreads + 1);
 }
 
-void zs_bufs(ZsBufs &z, uint64_t total_samples, uint32_t nreads)
+void zs_bufs(ZsBufs &z, uint64_t total_samples, uint32_t nreads, int method = PRESS_HIP_ZSTD_SVB_ZD)
 {
+	z.kdiv = method == PRESS_HIP_ZSTD_SVB12_ZD ? 8 : 4;
 	z.ztmp = (uint8_t *) g.ztmp.p;
 	z.zoff = (uint64_t *) g.zoff.p;
 	z.zoff4 = (uint64_t *) g.zoff4.p;
@@ -590,9 +591,10 @@ static int launch_press(int method, const BatchArgs &a, hipStream_t s)
 	case PRESS_HIP_SVB12_ZD: v1 ? launch_svb_encode(a, false, true, s) : launch_svb_encode_chunked(a, false, true, s); break;
 	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_encode(a, true, true, s) : launch_svb_encode_chunked(a, true, true, s); break;
 	case PRESS_HIP_SLOW5_SVB_ZD: launch_svb_encode_chunked(a, true, true, s, true); break;
-	case PRESS_HIP_ZSTD_SVB_ZD: {
+	case PRESS_HIP_ZSTD_SVB_ZD:
+	case PRESS_HIP_ZSTD_SVB12_ZD: {
 		ZsBufs z;
-		zs_bufs(z, g.zs_total, a.nreads);
+		zs_bufs(z, g.zs_total, a.nreads, method);
 		launch_zstd_encode(a, z, s);
 		break;
 	}
@@ -629,7 +631,7 @@ static int zs_host_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t s)
 	for (uint32_t r = 0; r < nr; r++) {
 		if (rd[r].mode != 3)
 			continue;
-		const uint64_t cap = 4ull + (caps[r] + 3ull) / 4 + 2ull * caps[r];
+		const uint64_t cap = 4ull + (caps[r] + (uint64_t) z.kdiv - 1) / z.kdiv + 2ull * caps[r];
 		frame.resize(ilen[r] + 8);
 		buf.resize(cap + 8);
 		HIPCHK(hipMemcpy(frame.data(), a.in + ioff[r], ilen[r], hipMemcpyDeviceToHost));
@@ -654,9 +656,10 @@ static int launch_depress(int method, const DecodeArgs &a, hipStream_t s)
 	case PRESS_HIP_SVB12_ZD: v1 ? launch_svb_decode(a, false, true, s) : launch_svb_decode_chunked(a, false, true, s); break;
 	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_decode(a, true, true, s) : launch_svb_decode_chunked(a, true, true, s); break;
 	case PRESS_HIP_SLOW5_SVB_ZD: launch_svb_decode_chunked(a, true, true, s, true); break;
-	case PRESS_HIP_ZSTD_SVB_ZD: {
+	case PRESS_HIP_ZSTD_SVB_ZD:
+	case PRESS_HIP_ZSTD_SVB12_ZD: {
 		ZsBufs z;
-		zs_bufs(z, g.zs_total, a.nreads);
+		zs_bufs(z, g.zs_total, a.nreads, method);
 		launch_zstd_decode_frames(a, z, s);
 		const int rc = zs_host_frames(a, z, s);
 		if (rc)

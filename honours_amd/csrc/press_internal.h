@@ -198,6 +198,7 @@ struct ZsBufs {
 	ZsDCtl *dctl;
 	uint32_t *zn;         // [nreads] sample count found in the stream
 	uint32_t cap_copy, cap_units, cap_trees;
+	uint32_t kdiv;        // samples per key byte of the inner stream: 4 (svb-zd) or 8 (svb16-zd)
 };
 void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s); // press_zstd.hip
 // decode in two steps: frames -> svb-zd streams in ztmp (reads the device leaves to libzstd

@@ -26,7 +26,6 @@ namespace {
 
 constexpr uint32_t ZB = zs::BLOCK_LITS;
 constexpr uint32_t RLE_MAX = 131072; // Block_Maximum_Size
-constexpr uint32_t KCH = CHUNK / 4;  // key bytes per chunk
 constexpr uint64_t ZFAIL = ~0ull;
 
 __device__ __forceinline__ uint64_t wave_incl64(uint64_t v, int lane)
@@ -77,20 +76,23 @@ __device__ __forceinline__ uint64_t wg_excl_scan64(uint64_t v, uint64_t *wsum, u
 	return before + inc - v;
 }
 
-__device__ __forceinline__ uint64_t zs_slot(uint32_t n)
+// key bytes of n samples: kdiv = 4 samples per key byte (svb32, zstd_svb_zd) or 8 (svb16, zstd_svb12_zd)
+__device__ __forceinline__ uint32_t zs_nk(uint32_t n, uint32_t kdiv) { return (uint32_t) (((uint64_t) n + kdiv - 1) / kdiv); }
+__device__ __forceinline__ uint64_t zs_slot(uint32_t n, uint32_t kdiv)
 {
 	// [u32 n][keys][data]: a 16-bit zig-zag delta is at most two bytes
-	return ((4ull + (n + 3ull) / 4 + 2ull * n + 16) + 15) & ~15ull;
+	return ((4ull + zs_nk(n, kdiv) + 2ull * n + 16) + 15) & ~15ull;
 }
 
 // where the svb-zd stream of every read goes in ztmp (one workgroup)
-__global__ __launch_bounds__(1024) void k_zs_layout(const uint32_t *nsamp, uint32_t nreads, uint64_t *zoff, uint64_t *zoff4)
+__global__ __launch_bounds__(1024) void k_zs_layout(const uint32_t *nsamp, uint32_t nreads, uint64_t *zoff, uint64_t *zoff4,
+						    uint32_t kdiv)
 {
 	__shared__ uint64_t wsum[16];
 	uint64_t carry = 0;
 	for (uint32_t base = 0; base <= nreads; base += 1024) {
 		const uint32_t r = base + threadIdx.x;
-		const uint64_t v = r < nreads ? zs_slot(nsamp[r]) : 0;
+		const uint64_t v = r < nreads ? zs_slot(nsamp[r], kdiv) : 0;
 		uint64_t total;
 		const uint64_t ex = wg_excl_scan64(v, wsum, &total);
 		if (r <= nreads) {
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(1024) void k_zs_layout(const uint32_t *nsamp, uint3
 
 // data blocks of every read (one workgroup): first_blk, the per-read record, the total
 __global__ __launch_bounds__(1024) void k_zs_blocks(const uint32_t *nsamp, const uint64_t *zlen, uint32_t nreads,
-						    uint32_t *first_blk, ZsRead *rd, uint32_t *nblocks, uint32_t max_blocks)
+						    uint32_t *first_blk, ZsRead *rd, uint32_t *nblocks, uint32_t max_blocks, uint32_t kdiv)
 {
 	__shared__ uint64_t wsum[16];
 	uint64_t carry = 0;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(1024) void k_zs_blocks(const uint32_t *nsamp, const
 			const uint32_t n = nsamp[r];
 			const uint64_t l = zlen[r];
 			ZsRead z;
-			z.nk = (uint32_t) (((uint64_t) n + 3) / 4);
+			z.nk = zs_nk(n, kdiv);
 			z.mode = 0;
 			z.knz = 0;
 			z.dbase = 0;
@@ -216,9 +218,11 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x)
 __device__ __forceinline__ uint32_t key_load(const ZsBufs &z, const ChunkDesc *dp, uint32_t *x, uint32_t *first)
 {
 	const uint32_t r = dp->read, j = dp->j;
-	const uint32_t nk = z.rd[r].nk;
+	const uint32_t kch = CHUNK / z.kdiv; // key bytes per chunk
+	const uint32_t end = (j + 1) * kch < z.rd[r].nk ? (j + 1) * kch : z.rd[r].nk;
+	const uint32_t nk = end; // (the keys of this chunk end here)
 	const uint8_t *keys = z.ztmp + z.zoff[r] + 4;
-	const uint32_t k0 = j * KCH + threadIdx.x * 32;
+	const uint32_t k0 = j * kch + threadIdx.x * 32;
 	*first = k0;
 	uint32_t cnt = 0;
 #pragma unroll
@@ -761,16 +765,16 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 {
 	if (!a.nreads)
 		return;
-	hipLaunchKernelGGL(k_zs_layout, dim3(1), dim3(1024), 0, s, a.nsamp, a.nreads, z.zoff, z.zoff4);
+	hipLaunchKernelGGL(k_zs_layout, dim3(1), dim3(1024), 0, s, a.nsamp, a.nreads, z.zoff, z.zoff4, z.kdiv);
 	BatchArgs sv = a; // the svb-zd stream of every read into ztmp, behind the place of its count
 	sv.out = z.ztmp;
 	sv.out_off = z.zoff4;
 	sv.out_len = z.zlen;
 	ktime_mute(true);
-	launch_svb_encode_chunked(sv, true, true, s);
+	launch_svb_encode_chunked(sv, z.kdiv == 4, true, s);
 	ktime_mute(false);
 	hipLaunchKernelGGL(k_zs_blocks, dim3(1), dim3(1024), 0, s, a.nsamp, z.zlen, a.nreads, z.first_blk, z.rd, z.nblocks,
-			   z.max_blocks);
+			   z.max_blocks, z.kdiv);
 	hipLaunchKernelGGL(k_zs_blockmap, dim3((z.max_blocks + 255) / 256), dim3(256), 0, s, z.first_blk, a.nreads, z.nblocks,
 			   z.blk_read);
 	(void) hipMemsetAsync(z.hist, 0, (size_t) a.nreads * 1024, s);
@@ -912,7 +916,7 @@ __global__ __launch_bounds__(64) void k_zs_walk(DecodeArgs a, ZsBufs z)
 	__shared__ zs::ReadWork work;
 	const uint32_t r = blockIdx.x;
 	const uint32_t cap_n = a.nsamp[r];
-	const uint64_t cap = 4ull + (cap_n + 3ull) / 4 + 2ull * cap_n; // what zs_slot() leaves room for
+	const uint64_t cap = 4ull + zs_nk(cap_n, z.kdiv) + 2ull * cap_n; // what zs_slot() leaves room for
 	DevSink sink{ z, a.in_off[r], z.zoff[r], r, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, false, 0, 0 };
 	int64_t L = zs::walk_frame(a.in + a.in_off[r], a.in_len[r], cap, sink, work);
 	sink.close_unit();
@@ -1246,7 +1250,7 @@ void launch_zstd_decode_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t
 	if (!a.nreads)
 		return;
 	(void) hipMemsetAsync(z.dctl, 0, sizeof(ZsDCtl), s);
-	hipLaunchKernelGGL(k_zs_layout, dim3(1), dim3(1024), 0, s, a.nsamp, a.nreads, z.zoff, z.zoff4);
+	hipLaunchKernelGGL(k_zs_layout, dim3(1), dim3(1024), 0, s, a.nsamp, a.nreads, z.zoff, z.zoff4, z.kdiv);
 	hipLaunchKernelGGL(k_zs_walk, dim3(a.nreads), dim3(64), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_copy, dim3(z.cap_copy < 8192 ? z.cap_copy : 8192), dim3(256), 0, s, a, z);
 	ktime_begin(1, s);
@@ -1265,7 +1269,7 @@ void launch_zstd_decode_streams(const DecodeArgs &a, const ZsBufs &z, hipStream_
 	sv.in_len = z.zlen;
 	sv.nsamp = z.zn;
 	ktime_mute(true);
-	launch_svb_decode_chunked(sv, true, true, s);
+	launch_svb_decode_chunked(sv, z.kdiv == 4, true, s);
 	ktime_mute(false);
 }
 

@@ -49,6 +49,9 @@ struct Work {
 	uint16_t cum[16];
 	uint16_t state_tab[64];
 	uint8_t spread[64];
+	// small tables (kept here rather than in locals: indexed at run time, and a GPU lane's
+	// locals of that kind live in scratch memory)
+	uint32_t bl[MAXLEN + 2], wc[13], norm[13], dfs[13], dnb[13];
 };
 
 ZS_FN uint32_t highbit(uint32_t v)
@@ -59,33 +62,45 @@ ZS_FN uint32_t highbit(uint32_t v)
 	return r;
 }
 
-// little-endian bit writer into a small byte buffer
+// little-endian bit writer into a small byte buffer: bits collect in a register, whole bytes
+// are stored (no read-modify-write of the buffer)
 struct Bits {
 	uint8_t *p;
-	uint32_t cap, pos; // pos in bits
+	uint32_t cap, bytes; // bytes stored
+	uint64_t acc;
+	uint32_t nacc;       // bits waiting in acc (< 8 between calls)
+	uint32_t pos;        // bits written in all
 	bool over;
 };
 ZS_FN void bits_init(Bits &b, uint8_t *p, uint32_t cap)
 {
 	b.p = p;
 	b.cap = cap;
+	b.bytes = 0;
+	b.acc = 0;
+	b.nacc = 0;
 	b.pos = 0;
 	b.over = false;
-	for (uint32_t i = 0; i < cap; i++)
-		p[i] = 0;
 }
-ZS_FN void bits_add(Bits &b, uint32_t v, uint32_t n)
+ZS_FN void bits_add(Bits &b, uint32_t v, uint32_t n) // n <= 32
 {
-	for (uint32_t i = 0; i < n; i++) {
-		const uint32_t q = b.pos + i;
-		if ((q >> 3) >= b.cap) {
-			b.over = true;
-			break;
-		}
-		if ((v >> i) & 1u)
-			b.p[q >> 3] |= (uint8_t) (1u << (q & 7u));
-	}
+	b.acc |= (uint64_t) (n < 32 ? v & ((1u << n) - 1u) : v) << b.nacc;
+	b.nacc += n;
 	b.pos += n;
+	while (b.nacc >= 8) {
+		if (b.bytes < b.cap)
+			b.p[b.bytes] = (uint8_t) b.acc;
+		else
+			b.over = true;
+		b.bytes++;
+		b.acc >>= 8;
+		b.nacc -= 8;
+	}
+}
+ZS_FN void bits_align(Bits &b) // pad the byte in progress with zeros
+{
+	if (b.nacc)
+		bits_add(b, 0, 8 - b.nacc);
 }
 
 // cnt[256]: occurrences; order[0..m): the bytes with cnt > 0, ascending by (cnt, byte); m >= 2.
@@ -117,7 +132,7 @@ ZS_FN void build_table(const uint32_t *cnt, const uint8_t *order, uint32_t m, Ta
 	}
 	// ---- depths, clamped to MAXLEN; bl[d] = bytes with a code of d bits.  Lengths are handed
 	// out in sorted order below (the rarest byte gets the longest code), so only the counts matter.
-	uint32_t bl[MAXLEN + 2];
+	uint32_t *bl = k.bl;
 	for (int i = 0; i <= MAXLEN + 1; i++)
 		bl[i] = 0;
 	k.depth[2 * m - 2] = 0;
@@ -238,7 +253,7 @@ ZS_FN void build_table(const uint32_t *cnt, const uint8_t *order, uint32_t m, Ta
 	}
 	// ---- FSE-compressed weights (FSE table log 6, the most HUF_readStats accepts)
 	constexpr uint32_t FL = 6, FS = 1u << FL;
-	uint32_t wc[13], norm[13];
+	uint32_t *wc = k.wc, *norm = k.norm;
 	for (int v = 0; v < 13; v++)
 		wc[v] = 0;
 	uint32_t maxw = 0;
@@ -305,10 +320,10 @@ ZS_FN void build_table(const uint32_t *cnt, const uint8_t *order, uint32_t m, Ta
 		}
 		if (remaining != 1)
 			return;
-		b.pos = (b.pos + 7) & ~7u; // the bit stream starts on the next byte
+		bits_align(b); // the bit stream starts on the next byte
 	}
 	// ---- the state table (FSE_buildCTable): spread, then the states of each value in table order
-	uint32_t dfs[13], dnb[13]; // deltaFindState (+64 to stay unsigned), deltaNbBits
+	uint32_t *dfs = k.dfs, *dnb = k.dnb; // deltaFindState (+64 to stay unsigned), deltaNbBits
 	{
 		const uint32_t step = (FS >> 1) + (FS >> 3) + 3;
 		uint32_t pos = 0, total = 0;
@@ -353,7 +368,8 @@ ZS_FN void build_table(const uint32_t *cnt, const uint8_t *order, uint32_t m, Ta
 		bits_add(b, st[0] & (FS - 1), FL);
 		bits_add(b, 1, 1); // end mark
 	}
-	const uint32_t bytes = (b.pos + 7) / 8;
+	bits_align(b);
+	const uint32_t bytes = b.bytes;
 	if (b.over || bytes > 127)
 		return;
 	t.desc[0] = (uint8_t) bytes;

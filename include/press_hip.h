@@ -169,7 +169,7 @@ enum press_hip_method {
 	PRESS_HIP_SVB_ZD           = 2,
 	PRESS_HIP_ZSTD_SVB_ZD      = 3,  /* "VBZ".  Per-read symbols: libzstd on the host, the reference's bytes.
 	                                    Batch API: the zstd frames are made and read ON THE DEVICE (below) */
-	PRESS_HIP_ZSTD_SVB12_ZD    = 4,  /* per-read API only */
+	PRESS_HIP_ZSTD_SVB12_ZD    = 4,  /* zstd(svb16-zd): as method 3 (per-read: libzstd on the host; batch: frames on the device) */
 	PRESS_HIP_VBE21_ZD         = 5,
 	PRESS_HIP_VBBE21_ZD        = 6,
 	PRESS_HIP_VBSBE21_ZD       = 7,

@@ -95,13 +95,17 @@ int zsm_table(const uint32_t *cnt, zs::Table *t)
 
 // S = [u32 n][keys (n+3)/4][data] (the buffer the reference gives to ZSTD_compress, press.c:1860)
 // -> frame; returns its size, 0 when it does not fit
-uint64_t zsm_frame(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap)
+uint64_t zsm_frame_k(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap, uint32_t kdiv);
+uint64_t zsm_frame(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap) { return zsm_frame_k(S, L, out, cap, 4); }
+
+// kdiv: samples per key byte - 4 for the svb-zd stream (zstd_svb_zd), 8 for svb16-zd (zstd_svb12_zd)
+uint64_t zsm_frame_k(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap, uint32_t kdiv)
 {
 	if (L < 4)
 		return raw_frame(S, L, out, cap);
 	uint32_t n;
 	memcpy(&n, S, 4);
-	const uint64_t nk = ((uint64_t) n + 3) / 4;
+	const uint64_t nk = ((uint64_t) n + kdiv - 1) / kdiv;
 	if (4 + nk > L)
 		return raw_frame(S, L, out, cap);
 	const uint8_t *keys = S + 4, *data = S + 4 + nk;

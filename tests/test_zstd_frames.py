@@ -62,21 +62,25 @@ def model():
             os.path.getmtime(MODEL_SRC), os.path.getmtime(os.path.join(ROOT, "honours_amd", "csrc", "zs_table.h"))):
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "zsmodel"], check=True)
     m = ctypes.CDLL(MODEL_SO)
-    m.zsm_frame.restype = ctypes.c_uint64
-    m.zsm_frame.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    m.zsm_frame_k.restype = ctypes.c_uint64
+    m.zsm_frame_k.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32]
 
-    def frame(buf):
+    def frame(buf, kdiv=4):
         a = np.frombuffer(buf, dtype=np.uint8).copy()
         out = np.zeros(len(buf) + len(buf) // 100 + 65536, dtype=np.uint8)
-        r = m.zsm_frame(a.ctypes.data, len(buf), out.ctypes.data, out.size)
+        r = m.zsm_frame_k(a.ctypes.data, len(buf), out.ctypes.data, out.size, kdiv)
         assert r
         return out[:r].tobytes()
     return frame
 
 
-def prezstd(oracle, s):
-    """the buffer the reference hands to ZSTD_compress (press.c:1860)"""
-    ret, c = oracle.press("svb_zd", s)
+# batch method -> (inner stream, samples per key byte)
+KINDS = {"zstd_svb_zd": ("svb_zd", 4), "zstd_svb12_zd": ("svb12_zd", 8)}
+
+
+def prezstd(oracle, s, inner="svb_zd"):
+    """the buffer the reference hands to ZSTD_compress (press.c:1860, 2020)"""
+    ret, c = oracle.press(inner, s)
     assert ret == 0
     return struct.pack("<I", len(s)) + c
 
@@ -98,13 +102,15 @@ def cases():
     return out
 
 
-def test_model_frames_decode_with_libzstd(model):
+@pytest.mark.parametrize("zm", sorted(KINDS))
+def test_model_frames_decode_with_libzstd(model, zm):
     z = _zstd()
     oracle = _libs.oracle()
+    inner, kdiv = KINDS[zm]
     raw = ours = theirs = 0
     for k, s in enumerate(cases()):
-        buf = prezstd(oracle, s)
-        f = model(buf)
+        buf = prezstd(oracle, s, inner)
+        f = model(buf, kdiv)
         assert zstd_decode(z, f, len(buf)) == buf, "case %d (n=%d)" % (k, len(s))
         assert len(f) <= 9 + len(buf) + 3 * ((len(buf) + 131071) // 131072)
         if k < 10:  # the NA12878-like reads
@@ -175,23 +181,25 @@ gpu = pytest.mark.gpu
 
 
 @gpu
-def test_device_frames_match_the_model_and_decode(model):
+@pytest.mark.parametrize("zm", sorted(KINDS))
+def test_device_frames_match_the_model_and_decode(model, zm):
     from honours_amd import press
     z = _zstd()
     oracle = _libs.oracle()
+    inner, kdiv = KINDS[zm]
     reads = cases()
-    frames = press.press_batch_host("zstd_svb_zd", reads)
+    frames = press.press_batch_host(zm, reads)
     for k, (s, f) in enumerate(zip(reads, frames)):
         assert f is not None, "case %d" % k
-        buf = prezstd(oracle, s)
+        buf = prezstd(oracle, s, inner)
         assert zstd_decode(z, f, len(buf)) == buf, "case %d (n=%d): libzstd" % (k, len(s))
-        assert f == model(buf), "case %d (n=%d): not the model's bytes" % (k, len(s))
+        assert f == model(buf, kdiv), "case %d (n=%d): not the model's bytes" % (k, len(s))
         if len(buf) > 2 * len(s):
             continue  # press.c:1896: the reference's decoder sizes its buffer for 2 bytes per sample (+ zstd's margin)
-        ret, back = oracle.depress("zstd_svb_zd", f, s.size)   # the oracle's decoder (libzstd + svb-zd)
+        ret, back = oracle.depress(zm, f, s.size)   # the oracle's decoder (libzstd + the inner stream's)
         assert ret == 0 and np.array_equal(back, s)
         if _libs.have_reference():
-            ret, back = _libs.reference().depress("zstd_svb_zd", f, s.size)
+            ret, back = _libs.reference().depress(zm, f, s.size)
             assert ret == 0 and np.array_equal(back, s)
 
 
@@ -236,10 +244,10 @@ def test_model_reader_on_both_kinds_of_frames(model):
     assert own > 10 and host > 10  # both paths are exercised
 
 
-def _libzstd_frames(z, oracle, reads, level=1):
+def _libzstd_frames(z, oracle, reads, level=1, inner="svb_zd"):
     out = []
     for s in reads:
-        buf = prezstd(oracle, s)
+        buf = prezstd(oracle, s, inner)
         a = np.frombuffer(buf, dtype=np.uint8).copy()
         o = np.zeros(len(buf) + len(buf) // 100 + 1024, dtype=np.uint8)
         r = z.ZSTD_compress(o.ctypes.data, o.size, a.ctypes.data, len(buf), level)
@@ -248,21 +256,23 @@ def _libzstd_frames(z, oracle, reads, level=1):
 
 
 @gpu
-def test_device_reads_its_own_frames():
+@pytest.mark.parametrize("zm", sorted(KINDS))
+def test_device_reads_its_own_frames(zm):
     from honours_amd import press
     reads = cases()
-    frames = press.press_batch_host("zstd_svb_zd", reads)
-    back = press.depress_batch_host("zstd_svb_zd", frames, [len(s) for s in reads])
+    frames = press.press_batch_host(zm, reads)
+    back = press.depress_batch_host(zm, frames, [len(s) for s in reads])
     for k, (s, b) in enumerate(zip(reads, back)):
         assert b is not None and np.array_equal(b, s), "case %d (n=%d)" % (k, len(s))
     # a larger slot than the read: the count in the stream decides (press.c:1901)
-    back = press.depress_batch_host("zstd_svb_zd", frames, [len(s) + 1000 for s in reads])
+    back = press.depress_batch_host(zm, frames, [len(s) + 1000 for s in reads])
     for s, b in zip(reads, back):
         assert b is not None and np.array_equal(b, s)
 
 
 @gpu
-def test_device_reads_libzstd_frames():
+@pytest.mark.parametrize("zm", sorted(KINDS))
+def test_device_reads_libzstd_frames(zm):
     """the reference's own streams (libzstd level 1, press.h:275): blocks without sequences on
     the device, the others through libzstd on the host - same samples either way"""
     from honours_amd import press
@@ -270,14 +280,14 @@ def test_device_reads_libzstd_frames():
     oracle = _libs.oracle()
     reads = cases()
     for level in (1, 3):
-        frames = _libzstd_frames(z, oracle, reads, level)
-        back = press.depress_batch_host("zstd_svb_zd", frames, [len(s) for s in reads])
+        frames = _libzstd_frames(z, oracle, reads, level, KINDS[zm][0])
+        back = press.depress_batch_host(zm, frames, [len(s) for s in reads])
         for k, (s, b) in enumerate(zip(reads, back)):
             assert b is not None and np.array_equal(b, s), "level %d case %d (n=%d)" % (level, k, len(s))
     # and the per-read symbol of the reference's interface reads a device-made frame
-    f = press.press_batch_host("zstd_svb_zd", reads[:2])
+    f = press.press_batch_host(zm, reads[:2])
     for s, fr in zip(reads[:2], f):
-        ret, b = press.depress("zstd_svb_zd", fr, len(s))
+        ret, b = press.depress(zm, fr, len(s))
         assert ret == 0 and np.array_equal(b, s)
 
 
