@@ -40,6 +40,7 @@ WORKLOADS = {
     "slow5_svb_zd": "NA12878-like synthetic reads, BLOW5's signal codec (slow5lib svb-zd: u32 count + svb32 of zig-zag deltas)",
     "zstd_svb_zd": "NA12878-like synthetic reads, full VBZ pipeline zstd(svb-zd) with the zstd frames made and read on the device (config 3)",
     "zstd_svb12_zd": "NA12878-like synthetic reads, zstd(svb16-zd) with the zstd frames made and read on the device",
+    "zstd_hasgam_vbsse21_zdq": "NA12878-like synthetic reads, zstd(ex-zd) with the zstd frames made and read on the device",
     "rc_vbe21_zd": "NA12878-like synthetic reads, ex split + order-0 adaptive range coder (rc_vbe21_zd; serial per read by format)",
 }
 
@@ -158,6 +159,7 @@ def main():
                 "rc_vbe21_zd": ("k_rcs_encode", "k_rcs_decode"),
                 "zstd_svb_zd": ("k_zs_encode", "k_zs_hdecode"),
                 "zstd_svb12_zd": ("k_zs_encode", "k_zs_hdecode"),
+                "zstd_hasgam_vbsse21_zdq": ("k_zs_encode", "k_zs_hdecode"),
                 "shuffman_vbe21_zd": ("k_huff_encode_chunked", "k_huff_decode_tiles")}.get(
                     m, ("k_low_encode_chunked", "k_low_decode_chunked<false>"))
         traffic = measured_traffic(m, R, args.seed, args.fixed_len)

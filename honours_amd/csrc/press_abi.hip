@@ -165,7 +165,14 @@ bool is_zstd(int m)
 	return m == PRESS_HIP_ZSTD_SVB_ZD || m == PRESS_HIP_ZSTD_SVB12_ZD || m == PRESS_HIP_ZSTD_HASGAM_ZDQ;
 }
 bool is_rc(int m) { return m == PRESS_HIP_RC_VBE21_ZD; }
-bool is_zs(int m) { return m == PRESS_HIP_ZSTD_SVB_ZD || m == PRESS_HIP_ZSTD_SVB12_ZD; } // zstd frames made on the device (batch API)
+bool is_zs(int m) { return m == PRESS_HIP_ZSTD_SVB_ZD || m == PRESS_HIP_ZSTD_SVB12_ZD || m == PRESS_HIP_ZSTD_HASGAM_ZDQ; } // zstd frames made on the device (batch API)
+int zs_inner(int m) { return m == PRESS_HIP_ZSTD_SVB_ZD ? PRESS_HIP_SVB_ZD : m == PRESS_HIP_ZSTD_SVB12_ZD ? PRESS_HIP_SVB12_ZD : PRESS_HIP_HASGAM_ZDQ; }
+uint32_t zs_kdiv(int m) { return m == PRESS_HIP_ZSTD_SVB_ZD ? 4 : m == PRESS_HIP_ZSTD_SVB12_ZD ? 8 : 0; }
+// bytes per sample the inner stream can take at most (device: zs_content_max)
+uint64_t zs_tmp_bytes(int m, uint64_t total_samples, uint32_t nreads)
+{
+	return (zs_kdiv(m) ? total_samples * 9 / 4 : total_samples * 9) + ((uint64_t) nreads + 1) * 128 + 64;
+}
 bool is_ex(int m) { return (m >= PRESS_HIP_VBE21_ZD && m <= PRESS_HIP_HASGAM_ZDQ) || is_rc(m); }
 int entropy_of(int m) { return is_shuff(m) ? 1 : is_rc(m) ? 2 : 0; }
 
@@ -324,7 +331,7 @@ uint32_t max_zblocks_of(uint64_t total_samples, uint32_t nreads)
 
 void zs_bufs(ZsBufs &z, uint64_t total_samples, uint32_t nreads, int method = PRESS_HIP_ZSTD_SVB_ZD)
 {
-	z.kdiv = method == PRESS_HIP_ZSTD_SVB12_ZD ? 8 : 4;
+	z.kdiv = zs_kdiv(method);
 	z.ztmp = (uint8_t *) g.ztmp.p;
 	z.zoff = (uint64_t *) g.zoff.p;
 	z.zoff4 = (uint64_t *) g.zoff4.p;
@@ -358,11 +365,16 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 {
 	if (g.meta.reserve(((size_t) nreads + 1) * sizeof(ReadMeta)))
 		return PRESS_HIP_EHIP;
+	if (is_zs(method)) { // whatever the inner stream's kernels need
+		const int rc = reserve_scratch(zs_inner(method), total_samples, nreads, decode);
+		if (rc)
+			return rc;
+	}
 	if (is_zs(method) && decode) {
 		ZsBufs z;
-		zs_bufs(z, total_samples, nreads);
+		zs_bufs(z, total_samples, nreads, method);
 		const size_t nr = (size_t) nreads + 1;
-		if (g.ztmp.reserve(total_samples * 9 / 4 + nr * 64 + 64) || g.zoff.reserve(nr * 8) || g.zoff4.reserve(nr * 8) ||
+		if (g.ztmp.reserve(zs_tmp_bytes(method, total_samples, nreads)) || g.zoff.reserve(nr * 8) || g.zoff4.reserve(nr * 8) ||
 		    g.zlen.reserve(nr * 8) || g.zrd.reserve(nr * sizeof(ZsRead)) || g.zn.reserve(nr * 4) ||
 		    g.zdcopy.reserve((size_t) z.cap_copy * sizeof(ZsCopy)) || g.zdhuf.reserve((size_t) z.cap_units * 8 * sizeof(ZsHuf)) ||
 		    g.zdunit.reserve((size_t) z.cap_units * sizeof(ZsUnit)) || g.zdtree.reserve((size_t) z.cap_trees * sizeof(ZsTree)) ||
@@ -372,7 +384,7 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 	if (is_zs(method) && !decode) {
 		const size_t mc = max_chunks_of(total_samples, nreads), mb = max_zblocks_of(total_samples, nreads);
 		const size_t nr = (size_t) nreads + 1;
-		if (g.ztmp.reserve(total_samples * 9 / 4 + nr * 64 + 64) || g.zoff.reserve(nr * 8) || g.zoff4.reserve(nr * 8) ||
+		if (g.ztmp.reserve(zs_tmp_bytes(method, total_samples, nreads)) || g.zoff.reserve(nr * 8) || g.zoff4.reserve(nr * 8) ||
 		    g.zlen.reserve(nr * 8) || g.zhist.reserve(nr * 1024) || g.ztab.reserve(nr * sizeof(zs::Table)) ||
 		    g.zfirst.reserve(nr * 4) || g.zblk.reserve(mb * 4) || g.zsbits.reserve(mb * 16) || g.zbpos.reserve(mb * 4) ||
 		    g.zbflag.reserve(mb) || g.zkcnt.reserve(mc * 4) || g.zkbase.reserve(mc * 4) ||
@@ -380,7 +392,7 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 		    g.ex_pos.reserve((total_samples + 64) * 4) || g.ex_val.reserve((total_samples + 64) * 4))
 			return PRESS_HIP_EHIP;
 	}
-	if (is_svb(method) || is_ex(method) || is_zs(method)) {
+	if (is_svb(method) || is_ex(method)) {
 		const size_t mc = max_chunks_of(total_samples, nreads);
 		if (g.chunks.reserve(mc * sizeof(ChunkDesc)) || g.gran.reserve(2 * mc * sizeof(uint64_t)) ||
 		    g.ctl.reserve(sizeof(ChunkCtl)) || g.first_chunk.reserve(((size_t) nreads + 1) * 4))
@@ -592,7 +604,8 @@ static int launch_press(int method, const BatchArgs &a, hipStream_t s)
 	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_encode(a, true, true, s) : launch_svb_encode_chunked(a, true, true, s); break;
 	case PRESS_HIP_SLOW5_SVB_ZD: launch_svb_encode_chunked(a, true, true, s, true); break;
 	case PRESS_HIP_ZSTD_SVB_ZD:
-	case PRESS_HIP_ZSTD_SVB12_ZD: {
+	case PRESS_HIP_ZSTD_SVB12_ZD:
+	case PRESS_HIP_ZSTD_HASGAM_ZDQ: {
 		ZsBufs z;
 		zs_bufs(z, g.zs_total, a.nreads, method);
 		launch_zstd_encode(a, z, s);
@@ -631,7 +644,13 @@ static int zs_host_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t s)
 	for (uint32_t r = 0; r < nr; r++) {
 		if (rd[r].mode != 3)
 			continue;
-		const uint64_t cap = 4ull + (caps[r] + (uint64_t) z.kdiv - 1) / z.kdiv + 2ull * caps[r];
+		uint64_t cap;
+		if (z.kdiv) {
+			cap = 4ull + (caps[r] + (uint64_t) z.kdiv - 1) / z.kdiv + 2ull * caps[r];
+		} else { // device: zs_content_max
+			const uint64_t vb = bound_vbzd(caps[r] ? caps[r] : 1);
+			cap = (vb + 3) / 4 + vb * 4 + 16;
+		}
 		frame.resize(ilen[r] + 8);
 		buf.resize(cap + 8);
 		HIPCHK(hipMemcpy(frame.data(), a.in + ioff[r], ilen[r], hipMemcpyDeviceToHost));
@@ -657,7 +676,8 @@ static int launch_depress(int method, const DecodeArgs &a, hipStream_t s)
 	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_decode(a, true, true, s) : launch_svb_decode_chunked(a, true, true, s); break;
 	case PRESS_HIP_SLOW5_SVB_ZD: launch_svb_decode_chunked(a, true, true, s, true); break;
 	case PRESS_HIP_ZSTD_SVB_ZD:
-	case PRESS_HIP_ZSTD_SVB12_ZD: {
+	case PRESS_HIP_ZSTD_SVB12_ZD:
+	case PRESS_HIP_ZSTD_HASGAM_ZDQ: {
 		ZsBufs z;
 		zs_bufs(z, g.zs_total, a.nreads, method);
 		launch_zstd_decode_frames(a, z, s);

@@ -150,7 +150,8 @@ struct ZsRead {               // per read
 	uint32_t knz;         // key bytes that are not zero
 	uint32_t mode;        // 0: RLE keys + Huffman data, 1: raw blocks, 2: failed
 	uint32_t dbase;       // frame offset of the first data block
-	uint32_t pad[3];
+	uint32_t plen;        // bytes in front of the keys: the count / the ex-zd header and exception section
+	uint32_t pad[2];
 };
 // ZsRead on the decode side: nd = content size of the frame, mode 0 ok / 2 malformed / 3 left to libzstd
 struct ZsCopy {               // content bytes [dst, dst + n) of ztmp: a copy of n bytes at src of the arena, or its byte n times
@@ -198,7 +199,7 @@ struct ZsBufs {
 	ZsDCtl *dctl;
 	uint32_t *zn;         // [nreads] sample count found in the stream
 	uint32_t cap_copy, cap_units, cap_trees;
-	uint32_t kdiv;        // samples per key byte of the inner stream: 4 (svb-zd) or 8 (svb16-zd)
+	uint32_t kdiv;        // samples per key byte of the inner stream: 4 (svb-zd), 8 (svb16-zd), 0: ex-zd (no keys)
 };
 void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s); // press_zstd.hip
 // decode in two steps: frames -> svb-zd streams in ztmp (reads the device leaves to libzstd

@@ -77,11 +77,20 @@ __device__ __forceinline__ uint64_t wg_excl_scan64(uint64_t v, uint64_t *wsum, u
 }
 
 // key bytes of n samples: kdiv = 4 samples per key byte (svb32, zstd_svb_zd) or 8 (svb16, zstd_svb12_zd)
-__device__ __forceinline__ uint32_t zs_nk(uint32_t n, uint32_t kdiv) { return (uint32_t) (((uint64_t) n + kdiv - 1) / kdiv); }
+__device__ __forceinline__ uint32_t zs_nk(uint32_t n, uint32_t kdiv) { return kdiv ? (uint32_t) (((uint64_t) n + kdiv - 1) / kdiv) : 0u; }
+// most bytes the inner stream of n samples can have
+__device__ __forceinline__ uint64_t zs_content_max(uint32_t n, uint32_t kdiv)
+{
+	if (kdiv) // [u32 n][keys][data]: a 16-bit zig-zag delta is at most two bytes
+		return 4ull + zs_nk(n, kdiv) + 2ull * n;
+	// ex-zd (hasgam_vbsse21_zdq): the reference's own bound, press.c:2575, 3411, 8461
+	const uint32_t m1 = n ? n - 1 : 0;
+	const uint64_t vb = 2 + (uint64_t) (1 + m1 * 0.2 * 6 + m1 * 0.8);
+	return (vb + 3) / 4 + vb * 4 + 16;
+}
 __device__ __forceinline__ uint64_t zs_slot(uint32_t n, uint32_t kdiv)
 {
-	// [u32 n][keys][data]: a 16-bit zig-zag delta is at most two bytes
-	return ((4ull + zs_nk(n, kdiv) + 2ull * n + 16) + 15) & ~15ull;
+	return ((zs_content_max(n, kdiv) + 16) + 15) & ~15ull;
 }
 
 // where the svb-zd stream of every read goes in ztmp (one workgroup)
@@ -105,7 +114,8 @@ __global__ __launch_bounds__(1024) void k_zs_layout(const uint32_t *nsamp, uint3
 
 // data blocks of every read (one workgroup): first_blk, the per-read record, the total
 __global__ __launch_bounds__(1024) void k_zs_blocks(const uint32_t *nsamp, const uint64_t *zlen, uint32_t nreads,
-						    uint32_t *first_blk, ZsRead *rd, uint32_t *nblocks, uint32_t max_blocks, uint32_t kdiv)
+						    uint32_t *first_blk, ZsRead *rd, uint32_t *nblocks, uint32_t max_blocks, uint32_t kdiv,
+						    uint8_t *ztmp, const uint64_t *zoff, const ReadMeta *meta)
 {
 	__shared__ uint64_t wsum[16];
 	uint64_t carry = 0;
@@ -120,12 +130,29 @@ __global__ __launch_bounds__(1024) void k_zs_blocks(const uint32_t *nsamp, const
 			z.mode = 0;
 			z.knz = 0;
 			z.dbase = 0;
-			z.pad[0] = z.pad[1] = z.pad[2] = 0;
-			if (l == ZFAIL || l < z.nk) {
+			z.pad[0] = z.pad[1] = 0;
+			// the prefix: the count (svb streams; it is put in front of the stream here) or the
+			// ex-zd header + exception section (whatever is not a one-byte value)
+			uint64_t body = l; // keys + data
+			if (kdiv) {
+				z.plen = 4;
+				uint8_t *c = ztmp + zoff[r];
+				c[0] = (uint8_t) n;
+				c[1] = (uint8_t) (n >> 8);
+				c[2] = (uint8_t) (n >> 16);
+				c[3] = (uint8_t) (n >> 24);
+			} else {
+				z.plen = meta[r].hdr + meta[r].seclen;
+				if (l != ZFAIL && (meta[r].status || l < z.plen || n == 0))
+					body = ZFAIL;
+				else if (l != ZFAIL)
+					body = l - z.plen;
+			}
+			if (body == ZFAIL || body < z.nk) {
 				z.nd = 0;
 				z.mode = 2;
 			} else {
-				z.nd = (uint32_t) (l - z.nk);
+				z.nd = (uint32_t) (body - z.nk);
 			}
 			nb = z.mode == 0 ? (z.nd + ZB - 1) / ZB : 0;
 			rd[r] = z;
@@ -169,7 +196,7 @@ __device__ __forceinline__ BlkU load_blk(const ZsBufs &z, uint32_t b)
 	const ZsRead *rd = z.rd + u.r;
 	const uint32_t nd = rd->nd;
 	u.R = nd - u.j * ZB < ZB ? nd - u.j * ZB : ZB;
-	u.data = z.ztmp + z.zoff[u.r] + 4 + rd->nk + (uint64_t) u.j * ZB;
+	u.data = z.ztmp + z.zoff[u.r] + rd->plen + rd->nk + (uint64_t) u.j * ZB;
 	return u;
 }
 
@@ -218,10 +245,10 @@ __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x)
 __device__ __forceinline__ uint32_t key_load(const ZsBufs &z, const ChunkDesc *dp, uint32_t *x, uint32_t *first)
 {
 	const uint32_t r = dp->read, j = dp->j;
-	const uint32_t kch = CHUNK / z.kdiv; // key bytes per chunk
+	const uint32_t kch = z.kdiv ? CHUNK / z.kdiv : 0; // key bytes per chunk
 	const uint32_t end = (j + 1) * kch < z.rd[r].nk ? (j + 1) * kch : z.rd[r].nk;
 	const uint32_t nk = end; // (the keys of this chunk end here)
-	const uint8_t *keys = z.ztmp + z.zoff[r] + 4;
+	const uint8_t *keys = z.ztmp + z.zoff[r] + z.rd[r].plen;
 	const uint32_t k0 = j * kch + threadIdx.x * 32;
 	*first = k0;
 	uint32_t cnt = 0;
@@ -459,9 +486,10 @@ __global__ __launch_bounds__(256) void k_zs_plan(BatchArgs a, ZsBufs z)
 			a.out_len[r] = ZFAIL;
 		return;
 	}
-	const uint32_t n = a.nsamp[r];
-	const uint32_t nk = rd->nk, nd = rd->nd, knz = rd->knz;
-	const uint64_t L = 4ull + nk + nd;
+	const uint32_t nk = rd->nk, nd = rd->nd, knz = rd->knz, plen = rd->plen;
+	const uint64_t L = (uint64_t) plen + nk + nd;
+	const uint32_t np = (plen + RLE_MAX - 1) / RLE_MAX; // raw blocks of the prefix
+	const uint8_t *S = z.ztmp + z.zoff[r];
 	const uint64_t cap = a.out_off[r + 1] - a.out_off[r];
 	uint8_t *out = a.out + a.out_off[r];
 	const uint32_t *kpos = a.ex_pos + a.off[r];
@@ -483,7 +511,8 @@ __global__ __launch_bounds__(256) void k_zs_plan(BatchArgs a, ZsBufs z)
 	}
 	const uint32_t tail = knz ? nk - 1 - kpos[knz - 1] : nk;
 	nkb += (tail + RLE_MAX - 1) / RLE_MAX;
-	const uint32_t dbase = 9 + 7 + 4 * nkb;
+	const uint32_t kbase0 = 9 + 3 * np + plen; // frame offset of the first key block
+	const uint32_t dbase = kbase0 + 4 * nkb;
 
 	// ---- data blocks: the first one that pays WITH the tree carries it
 	uint32_t F = 0xFFFFFFFFu;
@@ -560,12 +589,13 @@ __global__ __launch_bounds__(256) void k_zs_plan(BatchArgs a, ZsBufs z)
 		out[6] = (uint8_t) (L >> 8);
 		out[7] = (uint8_t) (L >> 16);
 		out[8] = (uint8_t) (L >> 24);
-		put_block_header(out + 9, nk == 0 && nd == 0, 0, 4);
-		out[12] = (uint8_t) n;
-		out[13] = (uint8_t) (n >> 8);
-		out[14] = (uint8_t) (n >> 16);
-		out[15] = (uint8_t) (n >> 24);
+		for (uint32_t at = 0; at < plen; at += RLE_MAX) {
+			const uint32_t len = plen - at < RLE_MAX ? plen - at : RLE_MAX;
+			put_block_header(out + 9 + at + 3 * (at / RLE_MAX), at + len == plen && nk == 0 && nd == 0, 0, len);
+		}
 	}
+	for (uint32_t i = lane; i < plen; i += 64) // the prefix itself
+		out[9 + 3 * (i / RLE_MAX + 1) + i] = S[i];
 	uint32_t kb = 0; // key blocks in front
 	for (uint32_t i = 0; i < knz; i += 64) {
 		uint32_t blocks = 0, gap = 0;
@@ -576,7 +606,7 @@ __global__ __launch_bounds__(256) void k_zs_plan(BatchArgs a, ZsBufs z)
 		}
 		const uint32_t inc = wave_incl32(blocks, lane);
 		if (i + lane < knz) {
-			uint8_t *p = out + 16 + 4ull * (kb + inc - blocks);
+			uint8_t *p = out + kbase0 + 4ull * (kb + inc - blocks);
 			for (uint32_t at = 0; at < gap; at += RLE_MAX, p += 4)
 				put_rle(p, gap - at < RLE_MAX ? gap - at : RLE_MAX, 0);
 			put_rle(p, 1, (uint8_t) kval[i + lane]);
@@ -584,7 +614,7 @@ __global__ __launch_bounds__(256) void k_zs_plan(BatchArgs a, ZsBufs z)
 		kb += __shfl(inc, 63);
 	}
 	if (lane == 0) {
-		uint8_t *p = out + 16 + 4ull * kb;
+		uint8_t *p = out + kbase0 + 4ull * kb;
 		for (uint32_t at = 0; at < tail; at += RLE_MAX, p += 4)
 			put_rle(p, tail - at < RLE_MAX ? tail - at : RLE_MAX, 0);
 	}
@@ -736,8 +766,7 @@ __global__ __launch_bounds__(256) void k_zs_rawframes(BatchArgs a, ZsBufs z)
 	const uint32_t r = blockIdx.x;
 	if (z.rd[r].mode != 1)
 		return;
-	const uint32_t n = a.nsamp[r];
-	const uint64_t L = 4ull + z.rd[r].nk + z.rd[r].nd;
+	const uint64_t L = (uint64_t) z.rd[r].plen + z.rd[r].nk + z.rd[r].nd;
 	uint8_t *out = a.out + a.out_off[r];
 	const uint8_t *S = z.ztmp + z.zoff[r];
 	if (threadIdx.x == 0) {
@@ -754,8 +783,7 @@ __global__ __launch_bounds__(256) void k_zs_rawframes(BatchArgs a, ZsBufs z)
 		}
 	}
 	for (uint64_t i = threadIdx.x; i < L; i += 256) {
-		const uint8_t v = i < 4 ? (uint8_t) (n >> (8 * i)) : S[i];
-		out[9 + 3 * (i / RLE_MAX + 1) + i] = v;
+		out[9 + 3 * (i / RLE_MAX + 1) + i] = S[i];
 	}
 }
 
@@ -766,15 +794,18 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 	if (!a.nreads)
 		return;
 	hipLaunchKernelGGL(k_zs_layout, dim3(1), dim3(1024), 0, s, a.nsamp, a.nreads, z.zoff, z.zoff4, z.kdiv);
-	BatchArgs sv = a; // the svb-zd stream of every read into ztmp, behind the place of its count
+	BatchArgs sv = a; // the inner stream of every read into ztmp (svb: behind the place of its count)
 	sv.out = z.ztmp;
-	sv.out_off = z.zoff4;
+	sv.out_off = z.kdiv ? z.zoff4 : z.zoff;
 	sv.out_len = z.zlen;
 	ktime_mute(true);
-	launch_svb_encode_chunked(sv, z.kdiv == 4, true, s);
+	if (z.kdiv)
+		launch_svb_encode_chunked(sv, z.kdiv == 4, true, s);
+	else
+		launch_ex_encode_chunked(sv, EXF_EXZD, 0, s);
 	ktime_mute(false);
 	hipLaunchKernelGGL(k_zs_blocks, dim3(1), dim3(1024), 0, s, a.nsamp, z.zlen, a.nreads, z.first_blk, z.rd, z.nblocks,
-			   z.max_blocks, z.kdiv);
+			   z.max_blocks, z.kdiv, z.ztmp, z.zoff, a.meta);
 	hipLaunchKernelGGL(k_zs_blockmap, dim3((z.max_blocks + 255) / 256), dim3(256), 0, s, z.first_blk, a.nreads, z.nblocks,
 			   z.blk_read);
 	(void) hipMemsetAsync(z.hist, 0, (size_t) a.nreads * 1024, s);
@@ -916,7 +947,7 @@ __global__ __launch_bounds__(64) void k_zs_walk(DecodeArgs a, ZsBufs z)
 	__shared__ zs::ReadWork work;
 	const uint32_t r = blockIdx.x;
 	const uint32_t cap_n = a.nsamp[r];
-	const uint64_t cap = 4ull + zs_nk(cap_n, z.kdiv) + 2ull * cap_n; // what zs_slot() leaves room for
+	const uint64_t cap = zs_content_max(cap_n, z.kdiv); // what zs_slot() leaves room for
 	DevSink sink{ z, a.in_off[r], z.zoff[r], r, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, false, 0, 0 };
 	int64_t L = zs::walk_frame(a.in + a.in_off[r], a.in_len[r], cap, sink, work);
 	sink.close_unit();
@@ -926,8 +957,8 @@ __global__ __launch_bounds__(64) void k_zs_walk(DecodeArgs a, ZsBufs z)
 	if (threadIdx.x)
 		return;
 	ZsRead rd;
-	rd.nk = rd.knz = rd.dbase = 0;
-	rd.pad[0] = rd.pad[1] = rd.pad[2] = 0;
+	rd.nk = rd.knz = rd.dbase = rd.plen = 0;
+	rd.pad[0] = rd.pad[1] = 0;
 	rd.nd = L >= 0 ? (uint32_t) L : 0;
 	rd.mode = L >= 0 ? 0 : L == zs::W_HOST ? 3 : 2;
 	z.rd[r] = rd;
@@ -1231,7 +1262,10 @@ __global__ __launch_bounds__(256) void k_zs_finish(DecodeArgs a, ZsBufs z)
 	const uint32_t cap_n = a.nsamp[r];
 	uint32_t n = cap_n ? cap_n : 1;
 	uint64_t len = 0; // too short for any read: the svb-zd decode reports the failure
-	if (rd.mode == 0 && rd.nd >= 4) {
+	if (!z.kdiv) { // ex-zd carries its own sample count; n[r] is the room
+		n = cap_n;
+		len = rd.mode == 0 ? rd.nd : 0;
+	} else if (rd.mode == 0 && rd.nd >= 4) {
 		const uint8_t *S = z.ztmp + z.zoff[r];
 		const uint32_t cnt = (uint32_t) S[0] | ((uint32_t) S[1] << 8) | ((uint32_t) S[2] << 16) | ((uint32_t) S[3] << 24);
 		if (cnt <= cap_n) { // press.c:1901: the count in the stream is what gets decoded
@@ -1263,13 +1297,16 @@ void launch_zstd_decode_streams(const DecodeArgs &a, const ZsBufs &z, hipStream_
 	if (!a.nreads)
 		return;
 	hipLaunchKernelGGL(k_zs_finish, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a, z);
-	DecodeArgs sv = a; // the svb-zd streams are in ztmp, behind their counts
+	DecodeArgs sv = a; // the inner streams are in ztmp (svb: behind their counts)
 	sv.in = z.ztmp;
-	sv.in_off = z.zoff4;
+	sv.in_off = z.kdiv ? z.zoff4 : z.zoff;
 	sv.in_len = z.zlen;
 	sv.nsamp = z.zn;
 	ktime_mute(true);
-	launch_svb_decode_chunked(sv, z.kdiv == 4, true, s);
+	if (z.kdiv)
+		launch_svb_decode_chunked(sv, z.kdiv == 4, true, s);
+	else
+		launch_ex_decode_chunked(sv, EXF_EXZD, 0, s);
 	ktime_mute(false);
 }
 

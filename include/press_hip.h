@@ -179,7 +179,7 @@ enum press_hip_method {
 	PRESS_HIP_SHUFF_VBSBE21_ZD = 11,
 	PRESS_HIP_SHUFF_VBSSE21_ZD = 12,
 	PRESS_HIP_HASGAM_ZDQ       = 13,
-	PRESS_HIP_ZSTD_HASGAM_ZDQ  = 14, /* per-read API only */
+	PRESS_HIP_ZSTD_HASGAM_ZDQ  = 14, /* zstd(ex-zd): as method 3 */
 	PRESS_HIP_SLOW5_SVB_ZD     = 15, /* BLOW5's signal codec (section 3) */
 	PRESS_HIP_RC_VBE21_ZD      = 16, /* vbe21 + order-0 range coder: one read per lane (serial format) */
 	PRESS_HIP_NMETHODS         = 17
@@ -247,11 +247,12 @@ int press_hip_depress_batch(int method, const uint8_t *in, const uint64_t *in_of
 			    uint32_t *out_n, int device_resident);
 
 /*
- * PRESS_HIP_ZSTD_SVB_ZD in the two calls above (replaces the ZSTD_compress /
- * ZSTD_decompress calls of press.c:1860-1910 for batches):
+ * PRESS_HIP_ZSTD_SVB_ZD, _ZSTD_SVB12_ZD and _ZSTD_HASGAM_ZDQ in the two calls above (SURVEY.md 8f-3,
+ * replaces the ZSTD_compress / ZSTD_decompress calls of press.c:1860-1910, 2020-2070, 8549-8589 for batches):
  *   press    writes one standard zstd frame (RFC 8878) per read whose content is the buffer
- *            the reference hands to ZSTD_compress ([u32 n][svb-zd stream]): a raw block with
- *            the count, RLE blocks for the key bytes, Huffman-coded literal blocks of 16 KiB
+ *            the reference hands to ZSTD_compress ([u32 n][svb stream], or the ex-zd stream): a raw
+ *            block with the count (ex-zd: header + exception section), RLE blocks for the svb key
+ *            bytes, the one-byte values in Huffman-coded literal blocks of 16 KiB
  *            (one table per read, no sequences).  Any zstd decoder reads it - the reference's
  *            zstd_svb_zd_depress_16 included; the BYTES are not libzstd's (they never were
  *            pinned: they depend on the libzstd version).  Size <= 9 + L + 3 * ceil(L / 128 KiB)

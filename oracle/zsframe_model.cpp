@@ -95,21 +95,28 @@ int zsm_table(const uint32_t *cnt, zs::Table *t)
 
 // S = [u32 n][keys (n+3)/4][data] (the buffer the reference gives to ZSTD_compress, press.c:1860)
 // -> frame; returns its size, 0 when it does not fit
-uint64_t zsm_frame_k(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap, uint32_t kdiv);
-uint64_t zsm_frame(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap) { return zsm_frame_k(S, L, out, cap, 4); }
-
-// kdiv: samples per key byte - 4 for the svb-zd stream (zstd_svb_zd), 8 for svb16-zd (zstd_svb12_zd)
+uint64_t zsm_frame_p(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap, uint64_t plen, uint64_t nk);
+// S = [u32 n][keys][data]; kdiv: samples per key byte - 4 for the svb-zd stream (zstd_svb_zd), 8 for
+// svb16-zd (zstd_svb12_zd)
 uint64_t zsm_frame_k(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap, uint32_t kdiv)
 {
 	if (L < 4)
 		return raw_frame(S, L, out, cap);
 	uint32_t n;
 	memcpy(&n, S, 4);
-	const uint64_t nk = ((uint64_t) n + kdiv - 1) / kdiv;
-	if (4 + nk > L)
+	return zsm_frame_p(S, L, out, cap, 4, ((uint64_t) n + kdiv - 1) / kdiv);
+}
+uint64_t zsm_frame(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap) { return zsm_frame_k(S, L, out, cap, 4); }
+
+// The general shape: S = [prefix: plen bytes, stored raw][keys: nk bytes, zero runs as RLE blocks]
+// [data: Huffman-coded].  zstd_hasgam_vbsse21_zdq (press.c:8554): prefix = the ex-zd header and
+// exception section, no keys, data = the one-byte values.
+uint64_t zsm_frame_p(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap, uint64_t plen, uint64_t nk)
+{
+	if (plen + nk > L || plen == 0)
 		return raw_frame(S, L, out, cap);
-	const uint8_t *keys = S + 4, *data = S + 4 + nk;
-	const uint64_t nd = L - 4 - nk;
+	const uint8_t *keys = S + plen, *data = S + plen + nk;
+	const uint64_t nd = L - plen - nk;
 
 	// the table of this read: every data byte counts; a lone byte value gets a partner
 	uint32_t cnt[256] = { 0 };
@@ -129,9 +136,12 @@ uint64_t zsm_frame_k(const uint8_t *S, uint64_t L, uint8_t *out, uint64_t cap, u
 	Out o{ buf.data(), buf.size(), 0, false };
 	frame_header(o, L);
 	const uint64_t nblocks = (nd + zs::BLOCK_LITS - 1) / zs::BLOCK_LITS;
-	// the count
-	o.block_header(nk == 0 && nd == 0, 0, 4);
-	o.put(S, 4);
+	// the prefix
+	for (uint64_t at = 0; at < plen; at += 131072) {
+		const uint64_t len = std::min<uint64_t>(plen - at, 131072);
+		o.block_header(at + len == plen && nk == 0 && nd == 0, 0, (uint32_t) len);
+		o.put(S + at, len);
+	}
 	// the keys: runs of zeros as RLE blocks of at most 128 KiB, every other key byte on its own
 	for (uint64_t i = 0; i < nk;) {
 		uint64_t j = i;

@@ -65,24 +65,38 @@ def model():
     m.zsm_frame_k.restype = ctypes.c_uint64
     m.zsm_frame_k.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32]
 
+    m.zsm_frame_p.restype = ctypes.c_uint64
+    m.zsm_frame_p.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                              ctypes.c_uint64]
+
     def frame(buf, kdiv=4):
         a = np.frombuffer(buf, dtype=np.uint8).copy()
         out = np.zeros(len(buf) + len(buf) // 100 + 65536, dtype=np.uint8)
-        r = m.zsm_frame_k(a.ctypes.data, len(buf), out.ctypes.data, out.size, kdiv)
+        if kdiv:
+            r = m.zsm_frame_k(a.ctypes.data, len(buf), out.ctypes.data, out.size, kdiv)
+        else:
+            # ex-zd (ex_zd.c:9): version, u64 n, q, u16 zd0, u32 nex, exception section, then one byte for
+            # every other sample: the prefix is what is in front of those bytes
+            n, = struct.unpack("<Q", buf[1:9])
+            nex, = struct.unpack("<I", buf[12:16])
+            r = m.zsm_frame_p(a.ctypes.data, len(buf), out.ctypes.data, out.size, len(buf) - (n - 1 - nex), 0)
         assert r
         return out[:r].tobytes()
     return frame
 
 
 # batch method -> (inner stream, samples per key byte)
-KINDS = {"zstd_svb_zd": ("svb_zd", 4), "zstd_svb12_zd": ("svb12_zd", 8)}
+KINDS = {"zstd_svb_zd": ("svb_zd", 4), "zstd_svb12_zd": ("svb12_zd", 8),
+         "zstd_hasgam_vbsse21_zdq": ("hasgam_vbsse21_zdq", 0)}
 
 
 def prezstd(oracle, s, inner="svb_zd"):
-    """the buffer the reference hands to ZSTD_compress (press.c:1860, 2020)"""
+    """the buffer the reference hands to ZSTD_compress (press.c:1860, 2020, 8554)"""
     ret, c = oracle.press(inner, s)
+    if ret != 0 and inner.startswith("hasgam"):
+        return None  # more exceptions than the reference's bound has room for (press.c:2575): no such stream
     assert ret == 0
-    return struct.pack("<I", len(s)) + c
+    return c if inner.startswith("hasgam") else struct.pack("<I", len(s)) + c
 
 
 def cases():
@@ -110,6 +124,8 @@ def test_model_frames_decode_with_libzstd(model, zm):
     raw = ours = theirs = 0
     for k, s in enumerate(cases()):
         buf = prezstd(oracle, s, inner)
+        if buf is None:
+            continue
         f = model(buf, kdiv)
         assert zstd_decode(z, f, len(buf)) == buf, "case %d (n=%d)" % (k, len(s))
         assert len(f) <= 9 + len(buf) + 3 * ((len(buf) + 131071) // 131072)
@@ -190,8 +206,10 @@ def test_device_frames_match_the_model_and_decode(model, zm):
     reads = cases()
     frames = press.press_batch_host(zm, reads)
     for k, (s, f) in enumerate(zip(reads, frames)):
-        assert f is not None, "case %d" % k
         buf = prezstd(oracle, s, inner)
+        if buf is None:
+            continue
+        assert f is not None, "case %d" % k
         assert zstd_decode(z, f, len(buf)) == buf, "case %d (n=%d): libzstd" % (k, len(s))
         assert f == model(buf, kdiv), "case %d (n=%d): not the model's bytes" % (k, len(s))
         if len(buf) > 2 * len(s):
@@ -248,6 +266,9 @@ def _libzstd_frames(z, oracle, reads, level=1, inner="svb_zd"):
     out = []
     for s in reads:
         buf = prezstd(oracle, s, inner)
+        if buf is None:
+            out.append(None)
+            continue
         a = np.frombuffer(buf, dtype=np.uint8).copy()
         o = np.zeros(len(buf) + len(buf) // 100 + 1024, dtype=np.uint8)
         r = z.ZSTD_compress(o.ctypes.data, o.size, a.ctypes.data, len(buf), level)
@@ -261,6 +282,10 @@ def test_device_reads_its_own_frames(zm):
     from honours_amd import press
     reads = cases()
     frames = press.press_batch_host(zm, reads)
+    if zm.startswith("zstd_hasgam"):  # reads with more exceptions than the format's bound allows have no stream
+        reads = [s for s, f in zip(reads, frames) if f is not None]
+        frames = [f for f in frames if f is not None]
+        assert len(reads) >= 60
     back = press.depress_batch_host(zm, frames, [len(s) for s in reads])
     for k, (s, b) in enumerate(zip(reads, back)):
         assert b is not None and np.array_equal(b, s), "case %d (n=%d)" % (k, len(s))
@@ -281,9 +306,10 @@ def test_device_reads_libzstd_frames(zm):
     reads = cases()
     for level in (1, 3):
         frames = _libzstd_frames(z, oracle, reads, level, KINDS[zm][0])
-        back = press.depress_batch_host(zm, frames, [len(s) for s in reads])
-        for k, (s, b) in enumerate(zip(reads, back)):
-            assert b is not None and np.array_equal(b, s), "level %d case %d (n=%d)" % (level, k, len(s))
+        keep = [k for k, f in enumerate(frames) if f is not None]
+        back = press.depress_batch_host(zm, [frames[k] for k in keep], [len(reads[k]) for k in keep])
+        for k, b in zip(keep, back):
+            assert b is not None and np.array_equal(b, reads[k]), "level %d case %d (n=%d)" % (level, k, len(reads[k]))
     # and the per-read symbol of the reference's interface reads a device-made frame
     f = press.press_batch_host(zm, reads[:2])
     for s, fr in zip(reads[:2], f):
