@@ -325,6 +325,20 @@ __global__ __launch_bounds__(256) void k_zs_keylist(BatchArgs a, ZsBufs z)
 	}
 }
 
+// the lanes of a wave inside zs::build_table
+struct WavePar {
+	uint32_t l;
+	__device__ uint32_t lane() const { return l; }
+	__device__ uint32_t lanes() const { return 64; }
+	__device__ void sync() const
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+	__device__ void inc(uint32_t *p) const { atomicAdd(p, 1u); }
+};
+
 // one wave per read: the Huffman table from the histogram, and the ranks of the key lists
 struct TabLds {
 	uint32_t cnt[256];
@@ -398,8 +412,7 @@ __global__ __launch_bounds__(256) void k_zs_table(BatchArgs a, ZsBufs z)
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-	if (lane == 0)
-		zs::build_table(L.cnt, L.order, present, L.t, L.k);
+	zs::build_table(L.cnt, L.order, present, L.t, L.k, WavePar{ (uint32_t) lane });
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -52,6 +52,7 @@ struct Work {
 	// small tables (kept here rather than in locals: indexed at run time, and a GPU lane's
 	// locals of that kind live in scratch memory)
 	uint32_t bl[MAXLEN + 2], wc[13], norm[13], dfs[13], dnb[13];
+	uint32_t fail;
 };
 
 ZS_FN uint32_t highbit(uint32_t v)
@@ -103,54 +104,104 @@ ZS_FN void bits_align(Bits &b) // pad the byte in progress with zeros
 		bits_add(b, 0, 8 - b.nacc);
 }
 
+// How the lanes of a wave share build_table: the host runs it with one "lane".
+struct Solo {
+	ZS_FN uint32_t lane() const { return 0; }
+	ZS_FN uint32_t lanes() const { return 1; }
+	ZS_FN void sync() const {}
+	ZS_FN void inc(uint32_t *p) const { ++*p; }
+};
+
 // cnt[256]: occurrences; order[0..m): the bytes with cnt > 0, ascending by (cnt, byte); m >= 2.
-ZS_FN void build_table(const uint32_t *cnt, const uint8_t *order, uint32_t m, Table &t, Work &k)
+// Every lane of `par` calls it with the same arguments (t, k shared between them); loops over
+// bytes / nodes are dealt out to the lanes, the chains that cannot be (the merge of the tree,
+// the length limiter, the FSE state machine) run on lane 0.
+template <class Par> ZS_FN void build_table(const uint32_t *cnt, const uint8_t *order, uint32_t m, Table &t, Work &k, const Par &par)
 {
-	for (int s = 0; s < 256; s++) {
+	const uint32_t me = par.lane(), nl = par.lanes();
+	for (uint32_t s = me; s < 256; s += nl) {
 		t.code[s] = 0;
 		t.len[s] = 0;
 	}
-	t.desc_len = 0;
-	t.table_log = 0;
-	t.ok = 0;
+	if (me == 0) {
+		t.desc_len = 0;
+		t.table_log = 0;
+		t.ok = 0;
+		k.fail = 0;
+	}
 	if (m < 2 || m > 256)
 		return;
-	// ---- Huffman tree by the two-queue method: leaves 0..m-1 (sorted), internal nodes m..2m-2
-	for (uint32_t i = 0; i < m; i++)
-		k.w[i] = cnt[order[i]];
-	uint32_t qi = 0, qn = m, next = m;
-	while (next < 2 * m - 1) {
-		uint32_t pick[2];
-		for (int j = 0; j < 2; j++) {
-			const bool leaf = qi < m && (qn >= next || k.w[qi] <= k.w[qn]);
-			pick[j] = leaf ? qi++ : qn++;
-		}
-		k.w[next] = k.w[pick[0]] + k.w[pick[1]];
-		k.parent[pick[0]] = (uint16_t) next;
-		k.parent[pick[1]] = (uint16_t) next;
-		next++;
-	}
-	// ---- depths, clamped to MAXLEN; bl[d] = bytes with a code of d bits.  Lengths are handed
-	// out in sorted order below (the rarest byte gets the longest code), so only the counts matter.
 	uint32_t *bl = k.bl;
-	for (int i = 0; i <= MAXLEN + 1; i++)
+	for (uint32_t i = me; i < m; i += nl)
+		k.w[i] = cnt[order[i]];
+	for (uint32_t i = me; i <= (uint32_t) MAXLEN + 1; i += nl)
 		bl[i] = 0;
-	k.depth[2 * m - 2] = 0;
-	for (int n = (int) (2 * m - 3); n >= 0; n--) {
-		const uint32_t d = (uint32_t) k.depth[k.parent[n]] + 1;
-		k.depth[n] = (uint8_t) (d > 255 ? 255 : d);
-		if ((uint32_t) n < m)
-			bl[d > (uint32_t) MAXLEN ? (uint32_t) MAXLEN : d]++;
+	par.sync();
+	// ---- Huffman tree by the two-queue method: leaves 0..m-1 (sorted), internal nodes m..2m-2
+	const uint32_t root = 2 * m - 2;
+	if (me == 0) {
+		uint32_t qi = 0, qn = m, next = m;
+		while (next < 2 * m - 1) {
+			uint32_t pick[2];
+			for (int j = 0; j < 2; j++) {
+				const bool leaf = qi < m && (qn >= next || k.w[qi] <= k.w[qn]);
+				pick[j] = leaf ? qi++ : qn++;
+			}
+			k.w[next] = k.w[pick[0]] + k.w[pick[1]];
+			k.parent[pick[0]] = (uint16_t) next;
+			k.parent[pick[1]] = (uint16_t) next;
+			next++;
+		}
+		k.parent[root] = (uint16_t) root;
 	}
+	par.sync();
+	// ---- depths.  One lane: from the root down (a parent has a larger index than its children).
+	// Many lanes: pointer jumping - every node doubles the distance to its marked ancestor,
+	// eight times for up to 255 levels.
+	if (nl == 1) {
+		k.depth[root] = 0;
+		for (int n = (int) root - 1; n >= 0; n--) {
+			const uint32_t d = (uint32_t) k.depth[k.parent[n]] + 1;
+			k.depth[n] = (uint8_t) (d > 255 ? 255 : d);
+		}
+	} else {
+		for (uint32_t n = me; n <= root; n += nl)
+			k.depth[n] = n == root ? 0 : 1;
+		par.sync();
+		for (int it = 0; it < 8; it++) {
+			uint16_t aa[8];
+			uint8_t dd[8];
+			int c = 0;
+			for (uint32_t n = me; n <= root && c < 8; n += nl, c++) {
+				const uint32_t a = k.parent[n];
+				aa[c] = k.parent[a];
+				dd[c] = (uint8_t) (k.depth[n] + k.depth[a]);
+			}
+			par.sync();
+			c = 0;
+			for (uint32_t n = me; n <= root && c < 8; n += nl, c++) {
+				k.parent[n] = aa[c];
+				k.depth[n] = dd[c];
+			}
+			par.sync();
+		}
+	}
+	// bl[d] = bytes with a code of d bits, clamped to MAXLEN.  Lengths are handed out in sorted
+	// order below (the rarest byte gets the longest code), so only the counts matter.
+	for (uint32_t n = me; n < m; n += nl) {
+		const uint32_t d = k.depth[n];
+		par.inc(&bl[d > (uint32_t) MAXLEN ? (uint32_t) MAXLEN : d]);
+	}
+	par.sync();
 	// ---- the clamp oversubscribes the code space by `debt` (units of 2^-MAXLEN).  Pay it back
 	// where it is cheapest: making the rarest byte of the d-bit class one bit longer frees
 	// 2^(MAXLEN-1-d) units for cnt bits; whatever was freed too much is spent on the most
 	// frequent bytes that fit (within 0.05 % of the package-merge optimum on nanopore reads)
-	{
+	if (me == 0) {
 		int64_t debt = -(int64_t) (1u << MAXLEN);
 		for (int d = 1; d <= MAXLEN; d++)
 			debt += (int64_t) bl[d] << (MAXLEN - d);
-		while (debt > 0) {
+		while (debt > 0 && !k.fail) {
 			int best = 0;
 			uint64_t bc = 0, bf = 1;
 			uint32_t first = 0; // index (sorted order) of the rarest byte of class d
@@ -170,14 +221,16 @@ ZS_FN void build_table(const uint32_t *cnt, const uint8_t *order, uint32_t m, Ta
 				best = MAXLEN - 1;
 				while (best > 1 && !bl[best])
 					best--;
-				if (!bl[best])
-					return;
+				if (!bl[best]) {
+					k.fail = 1;
+					break;
+				}
 			}
 			bl[best]--;
 			bl[best + 1]++;
 			debt -= (int64_t) 1 << (MAXLEN - 1 - best);
 		}
-		while (debt < 0) {
+		while (debt < 0 && !k.fail) {
 			int best = 0;
 			uint64_t bc = 0, bn = 1;
 			uint32_t end = 0; // one past the most frequent byte of class d
@@ -193,75 +246,94 @@ ZS_FN void build_table(const uint32_t *cnt, const uint8_t *order, uint32_t m, Ta
 					}
 				}
 			}
-			if (!best)
-				return;
+			if (!best) {
+				k.fail = 1;
+				break;
+			}
 			bl[best]--;
 			bl[best - 1]++;
 			debt += (int64_t) 1 << (MAXLEN - best);
 		}
-	}
-	// ---- lengths: the rarest bytes get the longest codes
-	{
-		uint32_t idx = 0;
-		for (int bits = MAXLEN; bits >= 1; bits--)
-			for (uint32_t j = 0; j < bl[bits]; j++)
-				t.len[order[idx++]] = (uint8_t) bits;
-		if (idx != m)
-			return;
-	}
-	uint32_t tl = MAXLEN;
-	while (tl > 1 && bl[tl] == 0)
-		tl--;
-	t.table_log = tl;
-	{ // Kraft equality (a zstd decoder refuses anything else)
+		// the table log, Kraft equality (a zstd decoder refuses anything else), and where the
+		// codes of each weight start in the decoder's table
+		uint32_t tl = MAXLEN, total = 0;
+		while (tl > 1 && bl[tl] == 0)
+			tl--;
+		for (uint32_t b = 1; b <= (uint32_t) MAXLEN; b++)
+			total += bl[b];
 		uint32_t kraft = 0;
 		for (uint32_t b = 1; b <= tl; b++)
 			kraft += bl[b] << (tl - b);
-		if (kraft != (1u << tl))
-			return;
-	}
-	// ---- codes as the decoder lays out its table (HUF_readDTableX1): by weight = tl + 1 - len
-	// ascending, equal weights by byte value ascending; code = table index >> (weight - 1)
-	{
+		if (kraft != (1u << tl) || total != m)
+			k.fail = 1;
+		t.table_log = tl;
 		uint32_t start = 0;
 		for (uint32_t wt = 1; wt <= tl; wt++) {
 			k.cum[wt] = (uint16_t) start;
 			start += bl[tl + 1 - wt] << (wt - 1);
 		}
-		for (int s = 0; s < 256; s++) {
-			if (!t.len[s])
-				continue;
-			const uint32_t wt = tl + 1 - t.len[s];
-			t.code[s] = (uint16_t) (k.cum[wt] >> (wt - 1));
-			k.cum[wt] = (uint16_t) (k.cum[wt] + (1u << (wt - 1)));
+	}
+	par.sync();
+	if (k.fail)
+		return;
+	const uint32_t tl = t.table_log;
+	// ---- lengths: the rarest bytes get the longest codes
+	for (uint32_t i = me; i < m; i += nl) {
+		uint32_t bits = MAXLEN, before = 0;
+		while (bits > 1 && before + bl[bits] <= i) {
+			before += bl[bits];
+			bits--;
 		}
+		t.len[order[i]] = (uint8_t) bits;
+	}
+	par.sync();
+	// ---- codes as the decoder lays out its table (HUF_readDTableX1): by weight = tl + 1 - len
+	// ascending, equal weights by byte value ascending; code = table index >> (weight - 1)
+	for (uint32_t s = me; s < 256; s += nl) {
+		const uint32_t l = t.len[s];
+		if (!l)
+			continue;
+		uint32_t rank = 0;
+		for (uint32_t q = 0; q < s; q++)
+			rank += t.len[q] == l;
+		const uint32_t wt = tl + 1 - l;
+		t.code[s] = (uint16_t) ((k.cum[wt] >> (wt - 1)) + rank);
 	}
 	// ---- tree description: the weights of bytes 0 .. last-1 (the last one is implied)
 	int last = 255;
 	while (!t.len[last])
 		last--;
 	const uint32_t nw = (uint32_t) last;
-	for (uint32_t s = 0; s < nw; s++)
+	for (uint32_t s = me; s < nw; s += nl)
 		k.weight[s] = t.len[s] ? (uint8_t) (tl + 1 - t.len[s]) : 0;
+	for (uint32_t v = me; v < 13; v += nl)
+		k.wc[v] = 0;
+	par.sync();
 	if (nw <= 128) { // direct: 4 bits each
-		t.desc[0] = (uint8_t) (127 + nw);
-		for (uint32_t i = 0; i < nw; i += 2)
+		for (uint32_t i = 2 * me; i < nw; i += 2 * nl)
 			t.desc[1 + i / 2] = (uint8_t) ((k.weight[i] << 4) | (i + 1 < nw ? k.weight[i + 1] : 0));
-		t.desc_len = 1 + (nw + 1) / 2;
-		t.ok = 1;
+		if (me == 0) {
+			t.desc[0] = (uint8_t) (127 + nw);
+			t.desc_len = 1 + (nw + 1) / 2;
+			t.ok = 1;
+		}
+		par.sync();
 		return;
 	}
 	// ---- FSE-compressed weights (FSE table log 6, the most HUF_readStats accepts)
 	constexpr uint32_t FL = 6, FS = 1u << FL;
 	uint32_t *wc = k.wc, *norm = k.norm;
-	for (int v = 0; v < 13; v++)
-		wc[v] = 0;
-	uint32_t maxw = 0;
-	for (uint32_t s = 0; s < nw; s++) {
-		wc[k.weight[s]]++;
-		if (k.weight[s] > maxw)
-			maxw = k.weight[s];
+	for (uint32_t s = me; s < nw; s += nl)
+		par.inc(&wc[k.weight[s]]);
+	par.sync();
+	if (me != 0) { // the rest is one chain
+		par.sync();
+		return;
 	}
+	uint32_t maxw = 12;
+	while (maxw && !wc[maxw])
+		maxw--;
+	bool fine = true;
 	{
 		uint32_t sum = 0, big = 0, distinct = 0;
 		for (uint32_t v = 0; v <= maxw; v++) {
@@ -272,16 +344,18 @@ ZS_FN void build_table(const uint32_t *cnt, const uint8_t *order, uint32_t m, Ta
 				big = v;
 		}
 		if (distinct < 2)
-			return; // one weight value only: FSE cannot carry the count (and such data does not shrink)
-		if (sum > FS && norm[big] <= sum - FS)
-			return;
-		norm[big] = norm[big] + FS - sum;
-		if (norm[big] >= FS)
-			return;
+			fine = false; // one weight value only: FSE cannot carry the count (and such data does not shrink)
+		if (fine && sum > FS && norm[big] <= sum - FS)
+			fine = false;
+		if (fine) {
+			norm[big] = norm[big] + FS - sum;
+			if (norm[big] >= FS)
+				fine = false;
+		}
 	}
 	Bits b;
 	bits_init(b, t.desc + 1, 127);
-	{ // the normalised counts (FSE_writeNCount)
+	if (fine) { // the normalised counts (FSE_writeNCount)
 		bits_add(b, FL - 5, 4);
 		int remaining = (int) FS + 1, threshold = (int) FS, nbits = (int) FL + 1;
 		uint32_t sym = 0;
@@ -311,70 +385,80 @@ ZS_FN void build_table(const uint32_t *cnt, const uint8_t *order, uint32_t m, Ta
 				count += max;
 			bits_add(b, (uint32_t) count, (uint32_t) (nbits - (count < max ? 1 : 0)));
 			prev0 = count == 1;
-			if (remaining < 1)
-				return;
+			if (remaining < 1) {
+				fine = false;
+				break;
+			}
 			while (remaining < threshold) {
 				nbits--;
 				threshold >>= 1;
 			}
 		}
 		if (remaining != 1)
-			return;
+			fine = false;
 		bits_align(b); // the bit stream starts on the next byte
 	}
-	// ---- the state table (FSE_buildCTable): spread, then the states of each value in table order
-	uint32_t *dfs = k.dfs, *dnb = k.dnb; // deltaFindState (+64 to stay unsigned), deltaNbBits
-	{
-		const uint32_t step = (FS >> 1) + (FS >> 3) + 3;
-		uint32_t pos = 0, total = 0;
-		for (uint32_t v = 0; v <= maxw; v++) {
-			for (uint32_t i = 0; i < norm[v]; i++) {
-				k.spread[pos] = (uint8_t) v;
-				pos = (pos + step) & (FS - 1);
+	if (fine) {
+		// ---- the state table (FSE_buildCTable): spread, then the states of each value in table order
+		uint32_t *dfs = k.dfs, *dnb = k.dnb; // deltaFindState (+64 to stay unsigned), deltaNbBits
+		{
+			const uint32_t step = (FS >> 1) + (FS >> 3) + 3;
+			uint32_t pos = 0, total = 0;
+			for (uint32_t v = 0; v <= maxw; v++) {
+				for (uint32_t i = 0; i < norm[v]; i++) {
+					k.spread[pos] = (uint8_t) v;
+					pos = (pos + step) & (FS - 1);
+				}
+				k.cum[v] = (uint16_t) total;
+				if (norm[v]) {
+					const uint32_t mbo = norm[v] > 1 ? FL - highbit(norm[v] - 1) : FL;
+					dnb[v] = (mbo << 16) - (norm[v] > 1 ? norm[v] << mbo : FS);
+					dfs[v] = total + FS - norm[v];
+				}
+				total += norm[v];
 			}
-			k.cum[v] = (uint16_t) total;
-			if (norm[v]) {
-				const uint32_t mbo = norm[v] > 1 ? FL - highbit(norm[v] - 1) : FL;
-				dnb[v] = (mbo << 16) - (norm[v] > 1 ? norm[v] << mbo : FS);
-				dfs[v] = total + FS - norm[v];
+			for (uint32_t u = 0; u < FS; u++) {
+				const uint32_t v = k.spread[u];
+				k.state_tab[k.cum[v]++] = (uint16_t) (FS + u);
 			}
-			total += norm[v];
 		}
-		for (uint32_t u = 0; u < FS; u++) {
-			const uint32_t v = k.spread[u];
-			k.state_tab[k.cum[v]++] = (uint16_t) (FS + u);
+		// ---- the weights backwards through two alternating states (FSE_compress_usingCTable):
+		// weight i lives in state (i & 1); the last weight of each state costs no bits
+		{
+			uint32_t st[2] = { 0, 0 };
+			bool have[2] = { false, false };
+			for (int i = (int) nw - 1; i >= 0; i--) {
+				const uint32_t v = k.weight[i];
+				const int q = i & 1;
+				if (!have[q]) {
+					const uint32_t nbo = (dnb[v] + (1u << 15)) >> 16;
+					const uint32_t val = (nbo << 16) - dnb[v];
+					st[q] = k.state_tab[(val >> nbo) + dfs[v] - FS];
+					have[q] = true;
+				} else {
+					const uint32_t nbo = (st[q] + dnb[v]) >> 16;
+					bits_add(b, st[q] & ((1u << nbo) - 1u), nbo);
+					st[q] = k.state_tab[(st[q] >> nbo) + dfs[v] - FS];
+				}
+			}
+			bits_add(b, st[1] & (FS - 1), FL); // FSE_flushCState: state 2, then state 1
+			bits_add(b, st[0] & (FS - 1), FL);
+			bits_add(b, 1, 1); // end mark
+		}
+		bits_align(b);
+		const uint32_t bytes = b.bytes;
+		if (!b.over && bytes <= 127) {
+			t.desc[0] = (uint8_t) bytes;
+			t.desc_len = 1 + bytes;
+			t.ok = 1;
 		}
 	}
-	// ---- the weights backwards through two alternating states (FSE_compress_usingCTable):
-	// weight i lives in state (i & 1); the last weight of each state costs no bits
-	{
-		uint32_t st[2];
-		bool have[2] = { false, false };
-		for (int i = (int) nw - 1; i >= 0; i--) {
-			const uint32_t v = k.weight[i];
-			const int q = i & 1;
-			if (!have[q]) {
-				const uint32_t nbo = (dnb[v] + (1u << 15)) >> 16;
-				const uint32_t val = (nbo << 16) - dnb[v];
-				st[q] = k.state_tab[(val >> nbo) + dfs[v] - FS];
-				have[q] = true;
-			} else {
-				const uint32_t nbo = (st[q] + dnb[v]) >> 16;
-				bits_add(b, st[q] & ((1u << nbo) - 1u), nbo);
-				st[q] = k.state_tab[(st[q] >> nbo) + dfs[v] - FS];
-			}
-		}
-		bits_add(b, st[1] & (FS - 1), FL); // FSE_flushCState: state 2, then state 1
-		bits_add(b, st[0] & (FS - 1), FL);
-		bits_add(b, 1, 1); // end mark
-	}
-	bits_align(b);
-	const uint32_t bytes = b.bytes;
-	if (b.over || bytes > 127)
-		return;
-	t.desc[0] = (uint8_t) bytes;
-	t.desc_len = 1 + bytes;
-	t.ok = 1;
+	par.sync();
+}
+
+ZS_FN void build_table(const uint32_t *cnt, const uint8_t *order, uint32_t m, Table &t, Work &k)
+{
+	build_table(cnt, order, m, t, k, Solo());
 }
 
 } // namespace zs
