@@ -1147,9 +1147,6 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	}
 	uint32_t *myin = sin[lane];
 	uint32_t *myout = sout[lane];
-#ifdef HD_SKIP
-	k = 0;
-#endif
 	for (uint32_t done = 0; __any(active && done < k); done += HD_SYMS) {
 		const bool go = active && done < k;
 		const uint32_t cnt = go ? (k - done < HD_SYMS ? k - done : HD_SYMS) : 0;
