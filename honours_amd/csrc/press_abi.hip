@@ -586,6 +586,13 @@ extern "C" uint64_t press_hip_bound(int method, uint32_t n)
 extern "C" uint64_t press_hip_workspace_bytes(int method, uint64_t total_samples, uint32_t nreads)
 {
 	uint64_t b = ((uint64_t) nreads + 1) * sizeof(ReadMeta);
+	if (is_zs(method)) { // the inner stream between the two stages dominates
+		b += press_hip_workspace_bytes(zs_inner(method), total_samples, nreads) + zs_tmp_bytes(method, total_samples, nreads) +
+		     (uint64_t) max_zblocks_of(total_samples, nreads) * 64 + ((uint64_t) nreads + 1) * (1024 + sizeof(zs::Table) + 64);
+		if (zs_kdiv(method))
+			b += 2 * (total_samples + 64) * 4; // the lists of non-zero key bytes
+		return b;
+	}
 	if (is_ex(method))
 		b += 2 * (total_samples + 64) * 4;
 	if (is_shuff(method))
