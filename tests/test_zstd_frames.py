@@ -338,3 +338,23 @@ def test_device_refuses_damaged_frames():
     # too small a slot for the count in the stream
     back = press.depress_batch_host("zstd_svb_zd", good[:2], [len(reads[0]), len(reads[1]) - 1])
     assert np.array_equal(back[0], reads[0]) and back[1] is None
+
+
+@gpu
+def test_device_frames_of_empty_and_tiny_reads():
+    """a batch that mixes an empty read, one-sample reads and a normal one (svb kinds: an empty read is a
+    frame of the bare count, as ZSTD_compress of press.c:1865 would see it)"""
+    from honours_amd import press
+    z = _zstd()
+    rng = np.random.default_rng(21)
+    reads = [np.zeros(0, dtype=np.int16), np.array([500], dtype=np.int16), rng.integers(300, 700, 30000).astype(np.int16),
+             np.array([-32768], dtype=np.int16), np.zeros(0, dtype=np.int16)]
+    for zm in ("zstd_svb_zd", "zstd_svb12_zd"):
+        frames = press.press_batch_host(zm, reads)
+        for s, f in zip(reads, frames):
+            assert f is not None
+            got = zstd_decode(z, f, 4 + 3 * len(s) + 16)
+            assert struct.unpack("<I", got[:4])[0] == len(s)
+        back = press.depress_batch_host(zm, frames, [max(1, len(s)) for s in reads])
+        for s, b in zip(reads, back):
+            assert b is not None and np.array_equal(b, s)
