@@ -203,13 +203,15 @@ __device__ __forceinline__ BlkU load_blk(const ZsBufs &z, uint32_t b)
 // byte histogram of one data block, added to the read's
 __global__ __launch_bounds__(256) void k_zs_hist(ZsBufs z)
 {
-	__shared__ uint32_t h[4][256];
+	// 16 copies (4 per wave, by lane): nanopore deltas are peaked, and lanes that hit the same
+	// counter in one instruction are served one after the other
+	__shared__ uint32_t h[16][256];
 	const uint32_t b = blockIdx.x;
 	if (b >= *z.nblocks)
 		return;
 	const BlkU u = load_blk(z, b);
-	const int w = threadIdx.x >> 6;
-	for (int i = 0; i < 4; i++)
+	uint32_t *mine = h[4 * (threadIdx.x >> 6) + (threadIdx.x & 3)];
+	for (int i = 0; i < 16; i++)
 		h[i][threadIdx.x] = 0;
 	__syncthreads();
 	const uint32_t i0 = threadIdx.x * 64;
@@ -224,14 +226,16 @@ __global__ __launch_bounds__(256) void k_zs_hist(ZsBufs z)
 			for (int d = 0; d < 4; d++)
 #pragma unroll
 				for (int e = 0; e < 4; e++)
-					atomicAdd(&h[w][(x[d] >> (8 * e)) & 0xFFu], 1u);
+					atomicAdd(&mine[(x[d] >> (8 * e)) & 0xFFu], 1u);
 		} else {
 			for (uint32_t e = at; e < u.R && e < at + 16; e++)
-				atomicAdd(&h[w][u.data[e]], 1u);
+				atomicAdd(&mine[u.data[e]], 1u);
 		}
 	}
 	__syncthreads();
-	const uint32_t c = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+	uint32_t c = 0;
+	for (int i = 0; i < 16; i++)
+		c += h[i][threadIdx.x];
 	if (c)
 		atomicAdd(&z.hist[(uint64_t) u.r * 256 + threadIdx.x], c);
 }
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(256) void k_zs_encode(BatchArgs a, ZsBufs z)
 {
 	__shared__ uint32_t enc[256];       // code | len << 16
 	__shared__ uint32_t stg_all[4][ZSTG];
-	__shared__ __attribute__((aligned(16))) uint8_t lit[4][4096];
+	__shared__ __attribute__((aligned(16))) uint8_t lit[4][4096]; // (padding the lanes' 64-byte runs apart: measured, no gain)
 	const uint32_t b = blockIdx.x;
 	if (b >= *z.nblocks)
 		return;
