@@ -358,3 +358,34 @@ def test_device_frames_of_empty_and_tiny_reads():
         back = press.depress_batch_host(zm, frames, [max(1, len(s)) for s in reads])
         for s, b in zip(reads, back):
             assert b is not None and np.array_equal(b, s)
+
+
+@gpu
+@pytest.mark.parametrize("zm", sorted(KINDS))
+def test_three_reads_fixture(zm):
+    """config 1 of BASELINE.json (data/three-reads.blow5, VBZ): the device's frames of the reference's own
+    reads are read by libzstd + the oracle, and are within 1 % of the size the reference got from libzstd
+    (tests/golden/three_reads.json: zstd_svb_zd 176598 bytes in all)"""
+    import json
+    from honours_amd import press
+    oracle = _libs.oracle()
+    gdir = os.path.join(ROOT, "tests", "golden")
+    meta = json.load(open(os.path.join(gdir, "three_reads.json")))
+    sig = np.fromfile(os.path.join(gdir, "three_reads.i16.bin"), dtype=np.int16)
+    reads, o = [], 0
+    for r in meta["reads"]:
+        reads.append(sig[o:o + r["n"]])
+        o += r["n"]
+    frames = press.press_batch_host(zm, reads)
+    ours = ref = 0
+    for r, s, f in zip(meta["reads"], reads, frames):
+        assert f is not None
+        ret, back = oracle.depress(zm, f, s.size)
+        assert ret == 0 and np.array_equal(back, s)
+        ours += len(f)
+        ref += r["methods"][zm]["len"]
+    assert ours <= ref * 1.01, (ours, ref)
+    back = press.depress_batch_host(zm, frames, [len(s) for s in reads])
+    for s, b in zip(reads, back):
+        assert np.array_equal(b, s)
+    print("%s on three-reads.blow5: %d bytes (the reference's libzstd: %d)" % (zm, ours, ref))
