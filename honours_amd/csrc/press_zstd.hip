@@ -1032,7 +1032,8 @@ constexpr uint32_t HD_IN = 96;   // stream bytes staged per round: 64 codes of a
 __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 {
 	__shared__ uint16_t dt2[2][2048];
-	__shared__ uint32_t sin[64][HD_IN / 4 + 1];   // odd stride: a lane's slot starts in its own bank (+1: a pair is read)
+	__shared__ uint32_t sin[64][HD_IN / 4 + 3];   // odd stride (27): a lane's slot starts in its own bank; one dword
+	                                              // of zeros in front of the bytes, one behind (a pair is read)
 	__shared__ uint32_t sout[64][HD_SYMS / 4 + 1];
 	const uint32_t total = z.dctl->nunits < z.cap_units ? z.dctl->nunits : z.cap_units;
 	if (2 * blockIdx.x >= total)
@@ -1139,29 +1140,29 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 			active = false;
 		}
 	}
-	uint64_t win = 0;
-	int have = 0;
-	int64_t nx = -1; // next stream byte to take, going down
-	if (active) {
-		const uint32_t lastb = p[len - 1];
-		const int hb = 31 - __builtin_clz(lastb);
-		win = hb ? (uint64_t) (lastb & ((1u << hb) - 1)) << (64 - hb) : 0;
-		have = hb;
-		nx = (int64_t) len - 2;
-	}
+	// The stream is read backwards from its end mark: bp = stream bits not yet used.  No bit
+	// window in registers (its 64-bit shifts run at a quarter of the rate and made this kernel
+	// VALU bound): the 11 bits below bp are cut out of the staged dwords at every step.
+	int32_t bp = 0;
+	bool overrun = false;
+	if (active)
+		bp = (int32_t) (8 * (len - 1)) + (31 - __builtin_clz((uint32_t) p[len - 1]));
 	uint32_t *myin = sin[lane];
 	uint32_t *myout = sout[lane];
+	myin[0] = 0; // stream byte base + j of a round sits at slot byte 4 + j: bits "below the stream" read as zeros
+	const uint32_t tsh = 11 - tl;
 	for (uint32_t done = 0; __any(active && done < k); done += HD_SYMS) {
 		const bool go = active && done < k;
 		const uint32_t cnt = go ? (k - done < HD_SYMS ? k - done : HD_SYMS) : 0;
-		// the HD_IN stream bytes up to nx: slot byte j is stream byte base + j.  All loads are
-		// issued before anything waits for one of them.
-		const int64_t base = nx > (int64_t) (HD_IN - 1) ? nx - (int64_t) (HD_IN - 1) : 0;
+		// the HD_IN stream bytes up to the one that holds bit bp - 1; a round of 64 codes uses at
+		// most 704 + 11 bits of them
+		const int32_t tb = bp > 0 ? (bp - 1) >> 3 : 0;
+		const int32_t base = tb >= (int32_t) HD_IN - 1 ? tb - ((int32_t) HD_IN - 1) : 0;
 		// six lanes share a stream's 96 bytes (16 each): a load instruction then reads ~11 runs
 		// of 96 bytes instead of 64 scattered pieces
 		{
 			const uint64_t pb = go ? (uint64_t) (uintptr_t) (p + base) : 0;
-			const uint32_t avail = go ? (uint32_t) ((int64_t) len - base < (int64_t) HD_IN ? (int64_t) len - base : (int64_t) HD_IN) : 0;
+			const uint32_t avail = go ? (uint32_t) ((int32_t) len - base < (int32_t) HD_IN ? (int32_t) len - base : (int32_t) HD_IN) : 0;
 			uint4 v[HD_IN / 16];
 			int oo[HD_IN / 16], kk[HD_IN / 16];
 #pragma unroll
@@ -1177,7 +1178,7 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 			}
 #pragma unroll
 			for (int c = 0; c < (int) HD_IN / 16; c++) {
-				uint32_t *row = sin[oo[c]] + 4 * kk[c];
+				uint32_t *row = sin[oo[c]] + 1 + 4 * kk[c];
 				row[0] = v[c].x;
 				row[1] = v[c].y;
 				row[2] = v[c].z;
@@ -1189,40 +1190,23 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 		}
 		if (go && base == 0 && len < HD_IN) { // a short stream: its last, partial 16 bytes one by one
 			for (uint32_t e = len & ~15u; e < len; e++) {
-				const uint32_t b = p[e];
-				myin[e >> 2] = (myin[e >> 2] & ~(0xFFu << (8 * (e & 3)))) | (b << (8 * (e & 3)));
+				const uint32_t b = p[e], at = e + 4;
+				myin[at >> 2] = (myin[at >> 2] & ~(0xFFu << (8 * (at & 3)))) | (b << (8 * (at & 3)));
 			}
 		}
 		uint32_t acc = 0;
-		int sl = (int) (nx - base); // slot byte of stream byte nx
-		// the next four stream bytes (slot bytes sl-3 .. sl) are read one refill ahead and shifted
-		// into place when they are used
-		uint32_t plo = myin[(sl >= 3 ? sl - 3 : 0) >> 2], phi = myin[((sl >= 3 ? sl - 3 : 0) >> 2) + 1];
+		const int32_t c0 = 32 - 11 - 8 * base; // slot bit of stream bit b: b + 32 - 8 base
 		for (uint32_t i = 0; i < cnt; i++) {
-			if (have <= 32) {
-				if (nx >= 3) {
-					const uint32_t pre = (uint32_t) ((((uint64_t) phi << 32) | plo) >> (8 * ((sl - 3) & 3)));
-					win |= (uint64_t) pre << (32 - have);
-					have += 32;
-					nx -= 4;
-					sl -= 4;
-					const int s3 = sl >= 3 ? sl - 3 : 0;
-					plo = myin[s3 >> 2];
-					phi = myin[(s3 >> 2) + 1];
-				} else {
-					while (have <= 56 && nx >= 0) {
-						const uint32_t b = (myin[sl >> 2] >> (8 * (sl & 3))) & 0xFFu;
-						win |= (uint64_t) b << (56 - have);
-						have += 8;
-						nx--;
-						sl--;
-					}
-				}
+			const uint32_t sb = (uint32_t) (bp + c0);
+			const uint32_t w0 = sb >> 5;
+			const uint32_t lo = myin[w0], hi = myin[w0 + 1];
+			const uint32_t v11 = __builtin_amdgcn_alignbit(hi, lo, sb & 31u) & 0x7FFu;
+			const uint32_t e = dt[v11 >> tsh];
+			bp -= (int32_t) (e >> 8);
+			if (bp < 0) { // more code bits than the stream has
+				overrun = true;
+				bp = 0;
 			}
-			const uint32_t e = dt[(uint32_t) (win >> (64 - tl))];
-			const uint32_t nb = e >> 8;
-			win <<= nb;
-			have -= (int) nb;
 			acc |= (e & 0xFFu) << (8 * (i & 3));
 			if ((i & 3) == 3) {
 				myout[i >> 2] = acc;
@@ -1257,7 +1241,7 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 		__builtin_amdgcn_wave_barrier();
 	}
 	if (active)
-		ok = have == 0 && nx < 0; // the stream ends exactly here
+		ok = bp == 0 && !overrun; // the stream ends exactly here
 	{
 		const unsigned long long bad = __ballot(!ok);
 		if ((bad & 0xFFFFFFFFull) && lane == 0)
