@@ -864,14 +864,24 @@ struct DevSink {
 	__device__ uint32_t take(uint32_t *ctr, uint32_t n = 1)
 	{
 		uint32_t i = 0;
-		if (threadIdx.x == 0)
+		if ((threadIdx.x & 63) == 0)
 			i = atomicAdd(ctr, n);
 		return (uint32_t) __shfl((int) i, 0);
+	}
+	// how the lanes share the loops of zs::read_tree
+	__device__ uint32_t lane() const { return threadIdx.x & 63; }
+	__device__ uint32_t lanes() const { return 64; }
+	__device__ uint32_t sum(uint32_t v) const { return wave_sum32(v); }
+	__device__ void sync() const
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	}
 	// frame bytes for the walk: the lanes share the loads
 	__device__ void fetch(uint8_t *dst, const uint8_t *src, uint32_t n)
 	{
-		for (uint32_t j = threadIdx.x; j < n; j += 64)
+		for (uint32_t j = threadIdx.x & 63; j < n; j += 64)
 			dst[j] = src[j];
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
@@ -879,7 +889,7 @@ struct DevSink {
 	}
 	__device__ void close_copies()
 	{
-		if (threadIdx.x == 0)
+		if ((threadIdx.x & 63) == 0)
 			for (uint32_t j = 0; j < cleft; j++)
 				if (cbase + j < z.cap_copy)
 					z.dcopy[cbase + j].n = 0;
@@ -901,7 +911,7 @@ struct DevSink {
 			c.dst = out_base + dst;
 			c.n = n;
 			c.fill = fill;
-			if (threadIdx.x == 0)
+			if ((threadIdx.x & 63) == 0)
 				z.dcopy[i] = c;
 		} else {
 			overflow = true;
@@ -911,7 +921,7 @@ struct DevSink {
 	__device__ void fill(uint64_t src, uint64_t dst, uint32_t n) { push_copy(src, dst, n, 1); }
 	__device__ void close_unit()
 	{
-		if (unit != 0xFFFFFFFFu && threadIdx.x == 0) {
+		if (unit != 0xFFFFFFFFu && (threadIdx.x & 63) == 0) {
 			ZsUnit u;
 			u.read = read;
 			u.tree = cur_tree;
@@ -929,9 +939,9 @@ struct DevSink {
 		if (i >= z.cap_trees)
 			return zs::W_HOST;
 		ZsTree *t = z.dtree + i;
-		for (int s = threadIdx.x; s < 256; s += 64)
+		for (int s = threadIdx.x & 63; s < 256; s += 64)
 			t->w[s] = w[s];
-		if (threadIdx.x == 0)
+		if ((threadIdx.x & 63) == 0)
 			t->tl = tl;
 		cur_tree = i;
 		return 0;
@@ -952,17 +962,21 @@ struct DevSink {
 		h.R = R;
 		h.four = four;
 		h.pad = 0;
-		if (threadIdx.x == 0)
+		if ((threadIdx.x & 63) == 0)
 			z.dhuf[(uint64_t) unit * ZU + ucount] = h;
 		ucount++;
 		return 0;
 	}
 };
 
-__global__ __launch_bounds__(64) void k_zs_walk(DecodeArgs a, ZsBufs z)
+// (four reads = four waves per workgroup: a CU holds twice as many waves that way)
+__global__ __launch_bounds__(256) void k_zs_walk(DecodeArgs a, ZsBufs z)
 {
-	__shared__ zs::ReadWork work;
-	const uint32_t r = blockIdx.x;
+	__shared__ zs::ReadWork works[4];
+	zs::ReadWork &work = works[threadIdx.x >> 6];
+	const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= a.nreads)
+		return;
 	const uint32_t cap_n = a.nsamp[r];
 	const uint64_t cap = zs_content_max(cap_n, z.kdiv); // what zs_slot() leaves room for
 	DevSink sink{ z, a.in_off[r], z.zoff[r], r, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, false, 0, 0 };
@@ -971,7 +985,7 @@ __global__ __launch_bounds__(64) void k_zs_walk(DecodeArgs a, ZsBufs z)
 	sink.close_copies();
 	if (L >= 0 && sink.overflow)
 		L = zs::W_HOST;
-	if (threadIdx.x)
+	if (threadIdx.x & 63)
 		return;
 	ZsRead rd;
 	rd.nk = rd.knz = rd.dbase = rd.plen = 0;
@@ -1284,7 +1298,7 @@ void launch_zstd_decode_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t
 		return;
 	(void) hipMemsetAsync(z.dctl, 0, sizeof(ZsDCtl), s);
 	hipLaunchKernelGGL(k_zs_layout, dim3(1), dim3(1024), 0, s, a.nsamp, a.nreads, z.zoff, z.zoff4, z.kdiv);
-	hipLaunchKernelGGL(k_zs_walk, dim3(a.nreads), dim3(64), 0, s, a, z);
+	hipLaunchKernelGGL(k_zs_walk, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_copy, dim3(z.cap_copy < 8192 ? z.cap_copy : 8192), dim3(256), 0, s, a, z);
 	ktime_begin(1, s);
 	hipLaunchKernelGGL(k_zs_hdecode, dim3((z.cap_units + 1) / 2), dim3(64), 0, s, a, z);

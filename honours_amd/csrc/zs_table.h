@@ -474,15 +474,14 @@ struct FwdBits {
 	const uint8_t *p;
 	uint32_t len, pos;
 };
-ZS_FN uint32_t fwd_peek(const FwdBits &b, uint32_t n)
+ZS_FN uint32_t fwd_peek(const FwdBits &b, uint32_t n) // n <= 16
 {
-	uint32_t v = 0;
-	for (uint32_t i = 0; i < n; i++) {
-		const uint32_t q = b.pos + i;
-		if ((q >> 3) < b.len && ((b.p[q >> 3] >> (q & 7u)) & 1u))
-			v |= 1u << i;
-	}
-	return v;
+	const uint32_t q = b.pos >> 3;
+	uint32_t w = 0;
+	for (uint32_t i = 0; i < 3; i++) // three bytes hold any 16 bits
+		if (q + i < b.len)
+			w |= (uint32_t) b.p[q + i] << (8 * i);
+	return (w >> (b.pos & 7u)) & ((1u << n) - 1u);
 }
 
 // ---- backward bit reader (FSE and Huffman streams): the last byte holds the end mark
@@ -498,14 +497,17 @@ ZS_FN bool back_init(BackBits &b, const uint8_t *p, uint32_t len)
 	b.pos = 8ll * (len - 1) + highbit(p[len - 1]);
 	return true;
 }
-ZS_FN uint32_t back_read(BackBits &b, uint32_t n) // the n bits below pos, the highest first
+ZS_FN uint32_t back_read(BackBits &b, uint32_t n) // the n <= 16 bits below pos, the highest first; zeros below bit 0
 {
 	uint32_t v = 0;
-	for (uint32_t i = 0; i < n; i++) {
-		const int64_t q = b.pos - 1 - i;
-		v <<= 1;
-		if (q >= 0 && ((b.p[q >> 3] >> (q & 7)) & 1u))
-			v |= 1u;
+	if (b.pos > 0 && n) {
+		const int64_t top = (b.pos - 1) >> 3; // byte of the highest bit wanted
+		uint32_t w = 0;                     // bytes top-2 .. top, top in bits 16..23
+		for (int i = 0; i < 3; i++)
+			if (top - i >= 0)
+				w |= (uint32_t) b.p[top - i] << (8 * (2 - i));
+		const uint32_t hi = 16 + (uint32_t) ((b.pos - 1) & 7); // position of that bit in w
+		v = hi + 1 >= n ? (w >> (hi + 1 - n)) & ((1u << n) - 1u) : (w << (n - hi - 1)) & ((1u << n) - 1u);
 	}
 	b.pos -= n;
 	return v;
@@ -638,34 +640,43 @@ ZS_FN uint32_t fse_read_weights(const uint8_t *src, uint32_t len, uint8_t *w, ui
 
 // tree description at p -> weights of all 256 bytes, the table log; returns the bytes used,
 // 0: malformed, 0xFFFFFFFF: valid but beyond what the device decoder holds (table log 12)
-ZS_FN uint32_t read_tree(const uint8_t *p, uint32_t avail, uint8_t *w, uint32_t *table_log, ReadWork &k)
+// (par: lane() / lanes() / sum() / sync() - how the lanes that run the walk together share the
+// loops over the weights; the host has one lane)
+template <class Par>
+ZS_FN uint32_t read_tree(const uint8_t *p, uint32_t avail, uint8_t *w, uint32_t *table_log, ReadWork &k, const Par &par)
 {
 	if (!avail)
 		return 0;
 	const uint32_t hb = p[0];
+	const uint32_t me = par.lane(), nl = par.lanes();
 	uint32_t n, used;
 	if (hb >= 128) {
 		n = hb - 127;
 		used = 1 + (n + 1) / 2;
 		if (used > avail)
 			return 0;
-		for (uint32_t i = 0; i < n; i++)
+		for (uint32_t i = me; i < n; i += nl)
 			w[i] = (i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4);
 	} else {
 		used = 1 + hb;
 		if (used > avail)
 			return 0;
-		n = fse_read_weights(p + 1, hb, w, 255, k);
+		n = fse_read_weights(p + 1, hb, w, 255, k); // every lane the same chain, the same stores
 		if (!n)
 			return 0;
 	}
-	uint32_t total = 0;
-	for (uint32_t i = 0; i < n; i++) {
-		if (w[i] > 11)
-			return 0;
-		total += (1u << w[i]) >> 1;
+	par.sync();
+	uint32_t total = 0, bad = 0, ones = 0;
+	for (uint32_t i = me; i < n; i += nl) {
+		const uint32_t wi = w[i];
+		bad += wi > 11;
+		total += (1u << (wi & 15)) >> 1;
+		ones += wi == 1;
 	}
-	if (!total)
+	total = par.sum(total);
+	bad = par.sum(bad);
+	ones = par.sum(ones);
+	if (bad || !total)
 		return 0;
 	const uint32_t tl = highbit(total) + 1;
 	if (tl > 12)
@@ -673,14 +684,14 @@ ZS_FN uint32_t read_tree(const uint8_t *p, uint32_t avail, uint8_t *w, uint32_t 
 	const uint32_t rest = (1u << tl) - total;
 	if (rest != (1u << highbit(rest)))
 		return 0;
-	w[n++] = (uint8_t) (highbit(rest) + 1);
-	uint32_t ones = 0;
-	for (uint32_t i = 0; i < n; i++)
-		ones += w[i] == 1;
+	const uint32_t lastw = highbit(rest) + 1;
+	ones += lastw == 1;
 	if (ones < 2 || (ones & 1))
 		return 0;
-	for (uint32_t i = n; i < 256; i++)
-		w[i] = 0;
+	par.sync();
+	for (uint32_t i = n + me; i < 256; i += nl)
+		w[i] = i == n ? (uint8_t) lastw : 0;
+	par.sync();
 	*table_log = tl;
 	return tl > (uint32_t) MAXLEN ? 0xFFFFFFFFu : used;
 }
@@ -803,7 +814,7 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, 
 					uint32_t tl;
 					const uint32_t dn = cs < (uint32_t) DESC_MAX ? cs : (uint32_t) DESC_MAX;
 					sink.fetch(k.desc, fp + src, dn);
-					const uint32_t used = read_tree(k.desc, dn, w, &tl, k);
+					const uint32_t used = read_tree(k.desc, dn, w, &tl, k, sink);
 					if (used == 0)
 						return W_BAD;
 					if (used == 0xFFFFFFFFu)

@@ -213,6 +213,10 @@ struct HostSink {
 	uint8_t *out;
 	uint16_t dt[4096];
 	uint32_t tl;
+	uint32_t lane() const { return 0; }
+	uint32_t lanes() const { return 1; }
+	uint32_t sum(uint32_t v) const { return v; }
+	void sync() const {}
 	void fetch(uint8_t *dst, const uint8_t *src, uint32_t n) { memcpy(dst, src, n); }
 	void copy(uint64_t src, uint64_t dst, uint32_t n) { memcpy(out + dst, f + src, n); }
 	void fill(uint64_t src, uint64_t dst, uint32_t n) { memset(out + dst, f[src], n); }
