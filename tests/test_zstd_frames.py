@@ -389,3 +389,45 @@ def test_three_reads_fixture(zm):
     for s, b in zip(reads, back):
         assert np.array_equal(b, s)
     print("%s on three-reads.blow5: %d bytes (the reference's libzstd: %d)" % (zm, ours, ref))
+
+
+@gpu
+def test_device_reader_on_many_damaged_frames():
+    """300 truncated / bit-flipped frames in one batch: whatever the host build of the same reader
+    (oracle/zsframe_model.cpp: zs::walk_frame) refuses, the device refuses; undamaged neighbours decode"""
+    from honours_amd import press
+    m = ctypes.CDLL(MODEL_SO)
+    m.zsm_decode.restype = ctypes.c_int64
+    m.zsm_decode.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    rng = np.random.default_rng(77)
+    base = [rng.integers(300, 700, int(n)).astype(np.int16) for n in (3000, 20000, 70000)]
+    good = press.press_batch_host("zstd_svb_zd", base)
+    reads, frames, verdict = [], [], []
+    for k in range(300):
+        j = k % 3
+        f = bytearray(good[j])
+        kind = k % 5
+        if kind == 0:
+            f = f[:int(rng.integers(0, len(f)))]
+        elif kind == 4:
+            pass  # undamaged
+        else:
+            for _ in range(int(rng.integers(1, 4))):
+                at = int(rng.integers(0, min(len(f), 64))) if rng.integers(0, 3) == 0 else int(rng.integers(0, len(f)))
+                f[at] ^= 1 << int(rng.integers(0, 8))
+        f = bytes(f) if len(f) else b"\0"
+        a = np.frombuffer(f, dtype=np.uint8).copy()
+        cap = 4 + (len(base[j]) + 3) // 4 + 2 * len(base[j])
+        out = np.zeros(cap + 64, dtype=np.uint8)
+        verdict.append(int(m.zsm_decode(a.ctypes.data, len(f), out.ctypes.data, cap)))
+        reads.append(base[j])
+        frames.append(f)
+    back = press.depress_batch_host("zstd_svb_zd", frames, [len(s) for s in reads])
+    refused = 0
+    for k, (s, b, v) in enumerate(zip(reads, back, verdict)):
+        if k % 5 == 4:
+            assert b is not None and np.array_equal(b, s), k
+        if v == -1:
+            assert b is None, "frame %d: the host reader refuses it, the device does not" % k
+            refused += 1
+    assert refused > 50
