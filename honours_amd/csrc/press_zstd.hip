@@ -1117,9 +1117,10 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	const uint32_t bi = (lane & 31) >> 2, q = lane & 3;
 	bool ok = true;
 	// ---- one lane per stream.  Global memory is touched in bulk only: per round of HD_SYMS
-	// bytes a lane copies the HD_IN stream bytes below its position into its LDS slot, decodes
-	// from there into its output slot and stores that slot (a load per refill and a store per
-	// four bytes would wait on each other: loads and stores share one counter on this part).
+	// bytes the lanes stage the HD_IN stream bytes below each lane's position in its LDS slot,
+	// a lane decodes from there into its output slot, and the lanes store the slots (loads and
+	// stores issued from inside the decoding loop wait on each other - they share one counter on
+	// this part - and scattered dword stores cost as much as the decoding itself).
 	const uint8_t *p = nullptr;
 	uint8_t *out = nullptr;
 	uint32_t len = 0, k = 0;
