@@ -2,9 +2,9 @@
 """bench.py - the reference's headline measurement on MI355X.
 
 Metric (BASELINE.json): raw-signal MB/s for compress + decompress (MB = 1e6 bytes of
-int16 signal, press/test.c's timing of X_press + X_depress) and the compression ratio,
-on NA12878-like reads.  The NA12878 500k-read set is not available offline, so the
-workload is its synthetic stand-in (honours_amd/synth.py: lengths, first samples,
+int16 signal, press/test.c's timing of X_press + X_depress) and the compression ratio
+against VBZ, on NA12878-like reads.  The NA12878 500k-read set is not available offline,
+so the workload is its synthetic stand-in (honours_amd/synth.py: lengths, first samples,
 zig-zag-delta symbol statistics and exception rate of the published tables).
 
 One "step" = one pass of the hot path over one device-resident batch of reads:
@@ -12,9 +12,17 @@ press_batch then depress_batch.  `value` = raw signal bytes of the batch / step 
 whole job over all ranks (each rank owns its own reads: weak scaling, no data-path
 collective; one RCCL all-reduce of the {raw, compressed, reads} totals at the end).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--method svb12_zd] [--reads R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--method M] [--reads R] [--fixed-len L]
 
-N > 1 is launched by the driver with torch.distributed.run (one rank per GPU).
+Defaults:
+  N = 1   headline = BASELINE.json config 4: exception split + static NA12878_zd Huffman
+          (shuffman_vbe21_zd, the method that meets "ratio >= VBZ"), 8192 NA12878-like reads.
+          The same run then measures config 2 (svb12_zd), config 3 (zstd_svb_zd, full VBZ) and
+          config 5's shape on one GPU as sub-records under "configs", each with its own roofline
+          and cpu_baseline, and the PCIe-inclusive host-buffer rate ("e2e_host").
+  N > 1   BASELINE.json config 5: fixed 200 000-sample reads, best method (shuffman_vbe21_zd),
+          4096 reads per GPU per step, launched by the driver with torch.distributed.run
+          (one rank per GPU).  No sub-records, no CPU leg.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -30,19 +38,204 @@ sys.path.insert(0, ROOT)
 
 VBZ_RATIO = 2.928430  # data/reads.blow5.test:11 (zstd-svb-zd on NA12878)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+HEADLINE = "shuffman_vbe21_zd"
+CONFIG5_LEN = 200000
+CONFIG5_READS = 4096
 
 WORKLOADS = {
-    "svb12_zd": "NA12878-like synthetic reads, zig-zag-delta + svb16 pack only (svb12_zd, no entropy stage)",
-    "svb_zd": "NA12878-like synthetic reads, zig-zag-delta + svb32 pack (svb_zd)",
-    "vbe21_zd": "NA12878-like synthetic reads, exception split (vbe21_zd)",
-    "hasgam_vbsse21_zdq": "NA12878-like synthetic reads, ex-zd (hasgam_vbsse21_zdq)",
-    "shuffman_vbe21_zd": "NA12878-like synthetic reads, ex split + static NA12878_zd Huffman (shuffman_vbe21_zd)",
-    "slow5_svb_zd": "NA12878-like synthetic reads, BLOW5's signal codec (slow5lib svb-zd: u32 count + svb32 of zig-zag deltas)",
-    "zstd_svb_zd": "NA12878-like synthetic reads, full VBZ pipeline zstd(svb-zd) with the zstd frames made and read on the device (config 3)",
-    "zstd_svb12_zd": "NA12878-like synthetic reads, zstd(svb16-zd) with the zstd frames made and read on the device",
-    "zstd_hasgam_vbsse21_zdq": "NA12878-like synthetic reads, zstd(ex-zd) with the zstd frames made and read on the device",
-    "rc_vbe21_zd": "NA12878-like synthetic reads, ex split + order-0 adaptive range coder (rc_vbe21_zd; serial per read by format)",
+    "svb12_zd": "zig-zag-delta + svb16 pack only (svb12_zd, no entropy stage; BASELINE config 2)",
+    "svb_zd": "zig-zag-delta + svb32 pack (svb_zd)",
+    "vbe21_zd": "exception split (vbe21_zd)",
+    "hasgam_vbsse21_zdq": "ex-zd (hasgam_vbsse21_zdq)",
+    "shuffman_vbe21_zd": "exception split + static NA12878_zd Huffman entropy stage (shuffman_vbe21_zd; BASELINE config 4)",
+    "slow5_svb_zd": "BLOW5's signal codec (slow5lib svb-zd: u32 count + svb32 of zig-zag deltas)",
+    "zstd_svb_zd": "full VBZ pipeline zstd(svb-zd), zstd frames made and read on the device (BASELINE config 3)",
+    "zstd_svb12_zd": "zstd(svb16-zd), zstd frames made and read on the device",
+    "zstd_hasgam_vbsse21_zdq": "zstd(ex-zd), zstd frames made and read on the device",
+    "rc_vbe21_zd": "exception split + order-0 adaptive range coder (rc_vbe21_zd; serial per read by format)",
+    "rcc_vbe21_zd": "exception split + order-1 adaptive range coder (rcc_vbe21_zd; serial per read by format)",
 }
+
+# (press kernel, depress kernel): the kernels press_hip_kernel_timing() brackets with HIP events
+KERNELS = {
+    "svb12_zd": ("k_svb_encode_chunked<false,true>", "k_svb_decode_chunked<false,true>"),
+    "svb_zd": ("k_svb_encode_chunked<true,true>", "k_svb_decode_chunked<true,true>"),
+    "slow5_svb_zd": ("k_svb_encode_chunked<true,true,true>", "k_svb_decode_chunked<true,true,true>"),
+    "rc_vbe21_zd": ("k_rcs_encode", "k_rcs_decode"),
+    "rcc_vbe21_zd": ("k_rcc_encode", "k_rcc_decode"),
+    "zstd_svb_zd": ("k_zs_encode", "k_zs_hdecode"),
+    "zstd_svb12_zd": ("k_zs_encode", "k_zs_hdecode"),
+    "zstd_hasgam_vbsse21_zdq": ("k_zs_encode", "k_zs_hdecode"),
+    "shuffman_vbe21_zd": ("k_huff_encode_chunked", "k_huff_decode_tiles"),
+}
+# what bounds the dominant kernel, from the counter passes kept in profiles/ (DESIGN.md section 4):
+# "hbm" = streams at the memory system's rate; "valu" = instruction issue (HBM time of its bytes is a fraction)
+LIMITER = {"shuffman_vbe21_zd": "valu", "zstd_svb_zd": "valu", "zstd_svb12_zd": "valu",
+           "zstd_hasgam_vbsse21_zdq": "valu", "rc_vbe21_zd": "valu (serial per read)",
+           "rcc_vbe21_zd": "valu (serial per read)"}
+
+
+def kernel_own_bytes(m, which, raw, comp, nsamp):
+    """Bytes the timed kernel itself has to move once (its share of the call's 2n + c):
+    the kernels of a multi-kernel pipeline hand intermediates to each other through HBM."""
+    if m.startswith("shuffman"):
+        # encode: samples in, payload out; decode (k_huff_decode_tiles): payload in, the one-byte
+        # values out (k_low_decode_chunked<true> then reads them and writes the samples)
+        return raw + comp if which == 0 else comp + nsamp
+    if m.startswith("zstd"):
+        # k_zs_encode: inner stream (1.25 B/sample) in, frame out; k_zs_hdecode: frame in, literals out
+        inner = nsamp * 5 // 4
+        return inner + comp if which == 0 else comp + nsamp
+    if m.startswith("rc"):
+        return nsamp + comp
+    return raw + comp
+
+
+def measured_traffic(m, reads, seed, fixed_len):
+    """HBM bytes per launch from the committed PMC passes (profiles/*traffic*.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections of MI355X_MICROARCH.md
+    applied; tools/traffic.sh) - only for the exact workload they were collected on.
+    -> (dict or None, file name or None).  Counters cannot be read inside a timed run."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        w = t.get("workload", {})
+        if (w.get("method"), w.get("reads_per_gpu"), w.get("seed"), w.get("fixed_len")) == (m, reads, seed, fixed_len):
+            return t.get("traffic_bytes_per_launch"), os.path.relpath(f, ROOT)
+    return None, None
+
+
+class Batch:
+    """A device-resident synthetic batch and the arena / index buffers of one method."""
+
+    def __init__(self, torch, press, synth, seed, first_read, R, dev, fixed_len):
+        self.R = R
+        self.fixed_len = fixed_len
+        sig, starts, n = synth.synth_batch_torch(seed, first_read, R, dev, fixed_len=fixed_len, align=64)
+        self.sig = torch.cat([sig, torch.zeros(64, dtype=torch.int16, device=dev)])
+        self.starts, self.n = starts, n
+        self.total_samples = int(n.sum())
+        self.raw_bytes = 2 * self.total_samples
+        self.d_off = torch.from_numpy(starts[:-1].astype(np.int64)).to(dev)
+        self.d_n = torch.from_numpy(n.astype(np.int32)).to(dev)
+        self.d_back = torch.zeros_like(self.sig)
+        self.d_outn = torch.zeros(R, dtype=torch.int32, device=dev)
+        self.d_len = torch.zeros(R, dtype=torch.int64, device=dev)
+        self.dev = dev
+
+    def arena(self, torch, press, m):
+        caps = np.array([press.bound(m, int(x)) for x in self.n], dtype=np.int64)
+        caps = (caps + 64 + 127) // 128 * 128
+        out_off = np.concatenate([[0], np.cumsum(caps)])
+        d_out = torch.empty(int(out_off[-1]) + 64, dtype=torch.uint8, device=self.dev)
+        d_out_off = torch.from_numpy(out_off).to(self.dev)
+        return caps, d_out, d_out_off, d_out_off[:-1].contiguous()
+
+
+def run_method(torch, press, shard, b, m, steps, warmup, world, dist, seed, check=True):
+    """warmup, verify, then time EXACTLY `steps` steps between barrier + synchronize pairs.
+    -> the record of this method (value over all ranks)."""
+    if m.startswith("shuffman"):
+        press.load_table()
+    caps, d_out, d_out_off, d_in_off = b.arena(torch, press, m)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        press.press_batch(m, b.sig, b.d_off, b.d_n, d_out, d_out_off, b.d_len)
+        if ev is not None:
+            ev[1].record()
+        press.depress_batch(m, d_out, d_in_off, b.d_len, b.d_back, b.d_off, b.d_n, b.d_outn)
+        if ev is not None:
+            ev[2].record()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    b.d_back.zero_()
+    for _ in range(max(warmup, 1) if check else warmup):
+        step()
+    torch.cuda.synchronize()
+    # correctness of what is being timed: lossless on the device, sizes sane
+    lens = b.d_len.cpu().numpy()
+    if check:
+        assert (lens > 0).all() and (lens < caps).all(), "%s: a read failed to compress" % m
+        assert bool((b.d_outn.cpu() == torch.from_numpy(b.n.astype(np.int32))).all()), "%s: sample counts" % m
+        assert torch.equal(b.d_back, b.sig), "%s: round trip is not lossless" % m
+    comp_bytes = int(lens.sum())
+
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    press.kernel_timing(True)  # HIP events around the dominant kernel of each call, on its launch stream
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+
+    elapsed = t1 - t0
+    press_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    depress_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+    kpress = press.kernel_times(0)
+    kdepress = press.kernel_times(1)
+    press.kernel_timing(False)
+    kpress_ms = float(np.mean(kpress)) if kpress else press_ms
+    kdepress_ms = float(np.mean(kdepress)) if kdepress else depress_ms
+    # the only collective: 24 bytes of totals (+ the slowest rank's time) over RCCL
+    raw_all, comp_all, reads_all, elapsed = shard.reduce_totals(b.raw_bytes, comp_bytes, b.R, elapsed, b.dev)
+
+    # Roofline (DESIGN.md section 4).  Algorithmic bytes of a call = sum over the batch of 2n (int16
+    # samples) + c (compressed stream), each crossing HBM once (SURVEY 8d).
+    #   call_*   the whole press_batch / depress_batch call (all its kernels): alg / whole_call_ms
+    #   achieved/frac  the dominant kernel alone, timed with HIP events on its launch stream, against the
+    #            bytes THAT kernel has to move (kernel_bytes) - for a single-kernel method these coincide
+    alg = b.raw_bytes + comp_bytes
+    kern = KERNELS.get(m, ("k_low_encode_chunked", "k_low_decode_chunked<false>"))
+    traffic, tsrc = measured_traffic(m, b.R, seed, b.fixed_len)
+
+    def roof(which, name, ms, call_ms, key):
+        own = kernel_own_bytes(m, which, b.raw_bytes, comp_bytes, b.total_samples)
+        gbps = own / (ms * 1e-3) / 1e9
+        call_gbps = alg / (call_ms * 1e-3) / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                "traffic": traffic.get(key) if traffic else None, "traffic_source": tsrc,
+                "kernel_bytes_per_launch": own, "avg_launch_ms": round(ms, 4),
+                "algorithmic_bytes_per_call": alg, "whole_call_ms": round(call_ms, 4),
+                "call_achieved": round(call_gbps, 1), "call_frac": round(call_gbps / HBM_PEAK_GBPS, 4),
+                "limiter": LIMITER.get(m, "hbm")}
+
+    r_press = roof(0, kern[0], kpress_ms, press_ms, "press")
+    r_depress = roof(1, kern[1], kdepress_ms, depress_ms, "depress")
+    dominant, other = (r_depress, r_press) if kdepress_ms >= kpress_ms else (r_press, r_depress)
+    ratio = raw_all / comp_all
+    return {
+        "value": round(raw_all / (elapsed / steps) / 1e6, 1),
+        "unit": "MB/s",
+        "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "config": {
+            "workload": ("synthetic %d-sample reads (BASELINE config 5 shape), " % b.fixed_len if b.fixed_len
+                         else "NA12878-like synthetic reads, ") + WORKLOADS[m],
+            "method": m,
+            "reads_per_gpu": b.R,
+            "samples_per_gpu": b.total_samples,
+            "mean_read_len": round(b.total_samples / b.R, 1),
+            "step": "press_batch + depress_batch, device resident",
+        },
+        "ratio": round(ratio, 6),
+        "ratio_vs_vbz": round(ratio / VBZ_RATIO, 6),
+        "press_MBps": round(b.raw_bytes / (press_ms * 1e-3) / 1e6, 1),
+        "depress_MBps": round(b.raw_bytes / (depress_ms * 1e-3) / 1e6, 1),
+        "roofline": dominant,
+        "roofline_other": other,
+    }
 
 
 def main():
@@ -50,11 +243,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--method", default="svb12_zd", choices=sorted(WORKLOADS))
-    ap.add_argument("--reads", type=int, default=8192, help="reads per GPU per step")
-    ap.add_argument("--fixed-len", type=int, default=None, help="config 5: fixed read length")
+    ap.add_argument("--method", default=None, choices=sorted(WORKLOADS),
+                    help="headline method (default %s)" % HEADLINE)
+    ap.add_argument("--reads", type=int, default=None, help="reads per GPU per step")
+    ap.add_argument("--fixed-len", type=int, default=None,
+                    help="fixed read length (config 5: %d, the default for --gpus > 1)" % CONFIG5_LEN)
     ap.add_argument("--seed", type=int, default=20261004)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
+    ap.add_argument("--no-sub", action="store_true", help="headline only: no sub-records, no e2e leg")
     ap.add_argument("--no-check", action="store_true", help=argparse.SUPPRESS)  # diagnostic kernel builds only
     args = ap.parse_args()
 
@@ -76,175 +272,108 @@ def main():
 
     press.load_library()
     press.use_torch_stream()
-    if args.method.startswith("shuffman"):
-        press.load_table()
-    m = args.method
+    explicit = args.method is not None or args.fixed_len is not None or args.reads is not None
+    m = args.method or HEADLINE
+    fixed_len = args.fixed_len
+    reads = args.reads
+    if world > 1 and fixed_len is None and args.reads is None and args.method is None:
+        fixed_len, reads = CONFIG5_LEN, CONFIG5_READS  # BASELINE.json config 5
+    if reads is None:
+        reads = CONFIG5_READS if fixed_len else 8192
 
     # ---- synthetic batch, generated on the device (never staged through PCIe)
-    first_read, R = shard.weak_shard(args.reads, rank)
-    sig, starts, n = synth.synth_batch_torch(args.seed, first_read, R, dev, fixed_len=args.fixed_len, align=64)
-    sig = torch.cat([sig, torch.zeros(64, dtype=torch.int16, device=dev)])
-    total_samples = int(n.sum())
-    raw_bytes = 2 * total_samples
-    d_off = torch.from_numpy(starts[:-1].astype(np.int64)).to(dev)
-    d_n = torch.from_numpy(n.astype(np.int32)).to(dev)
-    caps = np.array([press.bound(m, int(x)) for x in n], dtype=np.int64)
-    caps = (caps + 64 + 127) // 128 * 128
-    out_off = np.concatenate([[0], np.cumsum(caps)])
-    d_out = torch.empty(int(out_off[-1]) + 64, dtype=torch.uint8, device=dev)
-    d_out_off = torch.from_numpy(out_off).to(dev)
-    d_in_off = d_out_off[:-1].contiguous()
-    d_len = torch.zeros(R, dtype=torch.int64, device=dev)
-    d_back = torch.zeros_like(sig)
-    d_outn = torch.zeros(R, dtype=torch.int32, device=dev)
-
-    def step(ev=None):
-        if ev is not None:
-            ev[0].record()
-        press.press_batch(m, sig, d_off, d_n, d_out, d_out_off, d_len)
-        if ev is not None:
-            ev[1].record()
-        press.depress_batch(m, d_out, d_in_off, d_len, d_back, d_off, d_n, d_outn)
-        if ev is not None:
-            ev[2].record()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    # correctness of what is being timed: lossless on the device, sizes sane
-    lens = d_len.cpu().numpy()
-    if not args.no_check:
-        assert (lens > 0).all() and (lens < caps).all(), "a read failed to compress"
-        assert bool((d_outn.cpu() == torch.from_numpy(n.astype(np.int32))).all()), "sample counts"
-        assert torch.equal(d_back, sig), "round trip is not lossless"
-    comp_bytes = int(lens.sum())
-
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    press.kernel_timing(True)  # HIP events around the dominant kernel of each call, on its launch stream
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-
-    elapsed = t1 - t0
-    press_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    depress_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
-    kpress = press.kernel_times(0)
-    kdepress = press.kernel_times(1)
-    press.kernel_timing(False)
-    kpress_ms = float(np.mean(kpress)) if kpress else press_ms
-    kdepress_ms = float(np.mean(kdepress)) if kdepress else depress_ms
-    # the only collective: 24 bytes of totals (+ the slowest rank's time) over RCCL
-    raw_all, comp_all, reads_all, elapsed = shard.reduce_totals(raw_bytes, comp_bytes, R, elapsed, dev)
+    first_read, R = shard.weak_shard(reads, rank)
+    b = Batch(torch, press, synth, args.seed, first_read, R, dev, fixed_len)
+    out = run_method(torch, press, shard, b, m, args.steps, args.warmup, world, dist, args.seed,
+                     check=not args.no_check)
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = raw_all / (elapsed / args.steps) / 1e6
-        ratio = raw_all / comp_all
-        # Roofline: algorithmic bytes per launch = sum over the batch of
-        # 2n (int16 samples) + c (compressed stream), read + written once; the dominant kernel is
-        # the longer of the two main kernels, timed with HIP events on its own launch stream.
-        alg = raw_bytes + comp_bytes
-        kern = {"svb12_zd": ("k_svb_encode_chunked<false,true>", "k_svb_decode_chunked<false,true>"),
-                "svb_zd": ("k_svb_encode_chunked<true,true>", "k_svb_decode_chunked<true,true>"),
-                "slow5_svb_zd": ("k_svb_encode_chunked<true,true,true>", "k_svb_decode_chunked<true,true,true>"),
-                "rc_vbe21_zd": ("k_rcs_encode", "k_rcs_decode"),
-                "zstd_svb_zd": ("k_zs_encode", "k_zs_hdecode"),
-                "zstd_svb12_zd": ("k_zs_encode", "k_zs_hdecode"),
-                "zstd_hasgam_vbsse21_zdq": ("k_zs_encode", "k_zs_hdecode"),
-                "shuffman_vbe21_zd": ("k_huff_encode_chunked", "k_huff_decode_tiles")}.get(
-                    m, ("k_low_encode_chunked", "k_low_decode_chunked<false>"))
-        traffic = measured_traffic(m, R, args.seed, args.fixed_len)
-
-        def roof(name, ms, call_ms, key):
-            gbps = alg / (ms * 1e-3) / 1e9
-            return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
-                    "traffic": traffic.get(key) if traffic else None,
-                    "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(ms, 4),
-                    "whole_call_ms": round(call_ms, 4)}
-
-        r_press = roof(kern[0], kpress_ms, press_ms, "press")
-        r_depress = roof(kern[1], kdepress_ms, depress_ms, "depress")
-        dominant, other = (r_depress, r_press) if kdepress_ms >= kpress_ms else (r_press, r_depress)
-        out = {
+        line = {
             "metric": "raw-signal MB/s (compress+decompress)",
-            "value": round(value, 1),
+            "value": out["value"],
             "unit": "MB/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step": out["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u16",
             "data": "synthetic",
-            "config": {
-                "workload": WORKLOADS[m],
-                "method": m,
-                "reads_per_gpu": R,
-                "samples_per_gpu": total_samples,
-                "mean_read_len": round(total_samples / R, 1),
-                "step": "press_batch + depress_batch, device resident",
-            },
-            "ratio": round(ratio, 6),
-            "ratio_vs_vbz": round(ratio / VBZ_RATIO, 6),
-            "press_MBps": round(raw_bytes / (press_ms * 1e-3) / 1e6, 1),
-            "depress_MBps": round(raw_bytes / (depress_ms * 1e-3) / 1e6, 1),
-            "roofline": dominant,
-            "roofline_other": other,
         }
+        line.update({k: v for k, v in out.items() if k not in ("value", "unit", "ms_per_step")})
+        sub = world == 1 and not args.no_sub and not explicit
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(m, sig, starts, n)
-        print(json.dumps(out), flush=True)
+            line["cpu_baseline"] = cpu_baseline(m, b)
+        if sub:
+            # the other single-GPU configurations of BASELINE.json, measured the same way in this run
+            line["configs"] = {}
+            for key, mm in (("config2_svb12_zd", "svb12_zd"), ("config3_zstd_svb_zd", "zstd_svb_zd")):
+                rec = run_method(torch, press, shard, b, mm, args.steps, args.warmup, 1, dist, args.seed)
+                rec["steps"], rec["warmup"] = args.steps, args.warmup
+                if not args.no_cpu:
+                    rec["cpu_baseline"] = cpu_baseline(mm, b, budget_s=6.0)
+                line["configs"][key] = rec
+            line["e2e_host"] = e2e_host(torch, press, b, m)
+            del b
+            torch.cuda.empty_cache()
+            b5 = Batch(torch, press, synth, args.seed, 0, CONFIG5_READS, dev, CONFIG5_LEN)
+            rec = run_method(torch, press, shard, b5, m, args.steps, args.warmup, 1, dist, args.seed)
+            rec["steps"], rec["warmup"] = args.steps, args.warmup
+            line["configs"]["config5_shape_1gpu"] = rec
+        print(json.dumps(line), flush=True)
 
     if world > 1:
         dist.destroy_process_group()
 
 
-def measured_traffic(m, reads, seed, fixed_len):
-    """HBM bytes per launch of the main kernels from the committed PMC passes
-    (profiles/*traffic*.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
-    gfx950 corrections of MI355X_MICROARCH.md applied) - only for the exact workload they were
-    collected on; None otherwise."""
-    import glob
+def e2e_host(torch, press, b, m, nreads=2048):
+    """PCIe-inclusive rates - never `value`: the batch API with HOST buffers (device_resident = 0:
+    H2D of the samples, kernels, D2H of the streams; and back) on the first `nreads` reads of the
+    batch, from pageable memory and from page-locked memory (press_hip_host_alloc)."""
+    k = min(nreads, b.R)
+    host = b.sig[: int(b.starts[k])].cpu().numpy()
+    reads = [host[int(b.starts[r]): int(b.starts[r]) + int(b.n[r])] for r in range(k)]
+    raw = 2 * int(sum(len(r) for r in reads))
+    out = {"method": m, "reads": k, "raw_bytes": raw, "unit": "MB/s",
+           "what": "press_hip_press_batch / _depress_batch with host pointers (device_resident = 0), best of 3; "
+                   "includes H2D of the samples, D2H of the streams and back"}
+    for key, pinned in (("pageable", False), ("pinned", True)):
+        hb = press.HostBatch(m, reads, pinned=pinned)
+        best_p = best_d = 1e30
+        for _ in range(4):  # the first pass allocates scratch and staging
+            t0 = time.perf_counter()
+            hb.press()
+            best_p = min(best_p, time.perf_counter() - t0)
+        for _ in range(4):
+            t0 = time.perf_counter()
+            hb.depress()
+            best_d = min(best_d, time.perf_counter() - t0)
+        assert hb.lossless(), "e2e round trip"
+        hb.close()
+        out[key] = {"press_MBps": round(raw / best_p / 1e6, 1), "depress_MBps": round(raw / best_d / 1e6, 1),
+                    "value": round(raw / (best_p + best_d) / 1e6, 1)}
+    return out
 
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
-        try:
-            t = json.load(open(f))
-        except (OSError, ValueError):
-            continue
-        w = t.get("workload", {})
-        if (w.get("method"), w.get("reads_per_gpu"), w.get("seed"), w.get("fixed_len")) == (m, reads, seed, fixed_len):
-            return t.get("traffic_bytes_per_launch")
-    return None
 
-
-def cpu_baseline(m, sig, starts, n):
+def cpu_baseline(m, b, budget_s=10.0):
     """The reference itself (oracle/_ref, built in the dev container from the reference's
     own sources) or, failing that, the oracle's C restatement, timed on this host with the
     harness's semantics (fresh malloc per read, clock() around X_press / X_depress,
-    press/test.c:1756-1815) on a bounded sample of the same reads.  One thread."""
+    press/test.c:1756-1815) on a bounded sample of the same reads.  One thread (`value`), and
+    the same reads dealt out over the host threads this process may use (`all_cores`)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _libs
 
     kind = "reference" if _libs.have_reference() else "port"
     codec = _libs.reference() if kind == "reference" else _libs.oracle()
-    k = min(256, len(n))
-    host = sig[: int(starts[k])].cpu().numpy()
+    k = min(256, b.R)
+    host = b.sig[: int(b.starts[k])].cpu().numpy()
     parts, off = [], [0]
     for r in range(k):
-        parts.append(host[int(starts[r]): int(starts[r]) + int(n[r])])
-        off.append(off[-1] + int(n[r]))
+        parts.append(host[int(b.starts[r]): int(b.starts[r]) + int(b.n[r])])
+        off.append(off[-1] + int(b.n[r]))
     flat = np.concatenate(parts)
     off = np.array(off, dtype=np.uint64)
     raw = 2 * int(off[-1])
@@ -256,14 +385,15 @@ def cpu_baseline(m, sig, starts, n):
         ps = ds = 0.0
         passes = 0
         t0 = time.perf_counter()
-        while passes < 50 and time.perf_counter() - t0 < 10.0:
+        while passes < 50 and time.perf_counter() - t0 < budget_s:
             p, d, _ = codec.time_batch(m, flat, off, check=(passes == 0))
             ps += p
             ds += d
             passes += 1
+        all_cores = cpu_all_cores(codec, m, flat, off, budget_s / 2)
     finally:
         os.dup2(saved, 2)
-    ncpu = os.cpu_count()
+        os.close(devnull)
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -281,9 +411,51 @@ def cpu_baseline(m, sig, starts, n):
                   % (k, int(off[-1]), passes),
         "press_MBps": round(raw * passes / ps / 1e6, 1),
         "depress_MBps": round(raw * passes / ds / 1e6, 1),
+        "all_cores": all_cores,
         "host_cpu": model,
-        "host_cores_available": ncpu,
+        "host_cores_available": os.cpu_count(),
     }
+
+
+def cpu_all_cores(codec, m, flat, off, budget_s):
+    """The same reads, one slice per host thread (reads are independent: BASELINE.md 3b), wall
+    clock around the pool: raw bytes / seconds of press + depress together.  Threads = the CPUs
+    this process may run on, capped at 64."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        ncpu = os.cpu_count() or 1
+    nthr = max(1, min(ncpu, 64, len(off) - 1))
+    k = len(off) - 1
+    # deal the reads out so that every thread gets about the same number of samples
+    order = np.argsort(-(off[1:] - off[:-1]).astype(np.int64))
+    bins = [[] for _ in range(nthr)]
+    load = [0] * nthr
+    for r in order:
+        i = int(np.argmin(load))
+        bins[i].append(int(r))
+        load[i] += int(off[r + 1] - off[r])
+    jobs = []
+    for rs in bins:
+        parts = [flat[int(off[r]): int(off[r + 1])] for r in rs]
+        o = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+        jobs.append((np.concatenate(parts) if parts else np.zeros(0, np.int16), o))
+
+    def work(j):
+        if len(j[1]) > 1:
+            codec.time_batch(m, j[0], j[1], check=False)
+
+    passes, t0 = 0, time.perf_counter()
+    with ThreadPoolExecutor(nthr) as ex:
+        while passes < 20 and time.perf_counter() - t0 < budget_s:
+            list(ex.map(work, jobs))
+            passes += 1
+    dt = time.perf_counter() - t0
+    raw = 2 * int(off[-1])
+    return {"value": round(raw * passes / dt / 1e6, 1), "unit": "MB/s", "cores": nthr,
+            "sample": "the same %d reads dealt out over %d threads x %d passes, wall clock" % (k, nthr, passes)}
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpress_hip.so")
-SOURCES = ["press_kernels.hip", "press_chunked.hip", "press_huffman.hip", "press_rc.hip", "press_zstd.hip", "press_abi.hip", "blow5_reader.cpp"]
+SOURCES = ["press_sections.hip", "press_chunked.hip", "press_huffman.hip", "press_rc.hip", "press_zstd.hip", "press_abi.hip", "blow5_reader.cpp"]
 HEADERS = ["press_internal.h", os.path.join("..", "..", "include", "press_hip.h")]
 
 

@@ -1,7 +1,7 @@
 // press_abi.hip - host side of libpress_hip.so: the C ABI of include/press_hip.h.
 //
 // Mirrors the reference's per-method C interface (press/press.h) on top of the batch
-// kernels in press_kernels.hip.  There is NO CPU implementation of any codec in this
+// kernels in press_*.hip.  There is NO CPU implementation of any codec in this
 // file: every X_press / X_depress runs the HIP kernels and fails (-1 / *nout = 0)
 // when the device is unavailable.  The only third-party stage is libzstd for the
 // zstd_* compositions, which the reference itself delegates to libzstd (press.c:1464).
@@ -12,6 +12,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/press_hip.h"
@@ -46,9 +49,16 @@ extern "C" const char *press_hip_last_error(void) { return g_err; }
 
 namespace {
 
+struct DevBuf;
+DevBuf *g_bufs = nullptr; // every DevBuf links itself in here: press_hip_shutdown() cannot forget one
+
 struct DevBuf {
 	void *p = nullptr;
 	size_t cap = 0;
+	DevBuf *next;
+	DevBuf() : next(g_bufs) { g_bufs = this; }
+	DevBuf(const DevBuf &) = delete;
+	DevBuf &operator=(const DevBuf &) = delete;
 	// grow-only; contents are not preserved
 	int reserve(size_t n)
 	{
@@ -83,9 +93,8 @@ struct Ctx {
 	// scratch shared by both modes
 	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, hgran, cbits;
 	DevBuf ztmp, zoff, zoff4, zlen, zhist, ztab, zfirst, zblk, zsbits, zbpos, zbflag, zkcnt, zkbase, zrd, znb, zn, zdcopy, zdhuf, zdunit, zdtree, zdctl; // zstd frames
-	int use_v1 = -1; // PRESS_HIP_V1=1 selects the one-workgroup-per-read svb kernels (A/B)
 	// staging for host-pointer calls
-	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn;
+	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn, dense, dense_off;
 	uint64_t zs_total = 0; // total_samples of the batch in flight (sizes of the zstd scratch)
 	// static Huffman table currently on the device
 	bool have_table = false;
@@ -96,11 +105,19 @@ struct Ctx {
 };
 
 Ctx g;
+// One context per process (one process per GPU): calls from several host threads are serialised.
+std::recursive_mutex g_mu;
+#define API_LOCK std::lock_guard<std::recursive_mutex> api_lock_(g_mu)
+void staging_release(); // page-locked staging buffers of the host-pointer calls (below)
 
+// Every entry point that touches the device comes through here: HIP's current device is per
+// host thread, so it is selected again on every call (cheap), not only by the first caller.
 int ctx_init()
 {
-	if (g.ready)
+	if (g.ready) {
+		HIPCHK(hipSetDevice(g.device));
 		return 0;
+	}
 	int ndev = 0;
 	hipError_t e = hipGetDeviceCount(&ndev);
 	if (e != hipSuccess || ndev == 0)
@@ -195,11 +212,16 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 	std::vector<HuffDev> hv(1);
 	HuffDev &h = hv[0];
 	memset(&h, 0xFF, sizeof h); // lut = 0xFFFF, child/leaf = -1
-	int nnodes = 1;
+	int nnodes = 1, ncoded = 0;
 	for (int s = 0; s < 256; s++) {
 		const uint32_t l = len[s];
-		if (l == 0 || l > 24)
-			return fail(PRESS_HIP_EARG, "Huffman table: symbol %d has code length %u (need 1..24)", s, l);
+		if (l > 24) // huffman.c takes codes of up to 255 bits; the device tables stop at 24 (press_hip.h)
+			return fail(PRESS_HIP_EARG, "Huffman table: symbol %d has a code of %u bits (at most 24)", s, l);
+		if (l == 0) { // a table file may list fewer than 256 symbols (huffman.c:549): such a symbol
+			h.enc[s] = 0; // has no code, and a read fails only if the symbol occurs (k_ex_scan_chunked)
+			continue;
+		}
+		ncoded++;
 		h.enc[s] = (uint32_t) (bits[s] & 0xFFFFFFu) | (l << 24);
 		int p = 0;
 		for (uint32_t k = 0; k < l; k++) {
@@ -279,9 +301,13 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 			h.lut32[i] = v;
 		}
 	}
+	if (!ncoded)
+		return fail(PRESS_HIP_EARG, "Huffman table: no symbol has a code");
 	h.minlen = 64;
 	h.maxlen = 0;
 	for (int s = 0; s < 256; s++) {
+		if (!len[s])
+			continue;
 		h.minlen = len[s] < h.minlen ? len[s] : h.minlen;
 		h.maxlen = len[s] > h.maxlen ? len[s] : h.maxlen;
 	}
@@ -307,21 +333,14 @@ uint32_t max_htiles_of(uint64_t total_samples, uint32_t nreads)
 {
 	uint32_t minlen = 64, maxlen = 1;
 	for (int s = 0; s < 256; s++) {
+		if (!g.tlen[s])
+			continue;
 		minlen = g.tlen[s] < minlen ? g.tlen[s] : minlen;
 		maxlen = g.tlen[s] > maxlen ? g.tlen[s] : maxlen;
 	}
 	const uint64_t tb = (uint64_t) HUF_HT * (minlen >= 4 ? 128u : minlen >= 2 ? 64u : 32u);
 	const uint64_t mt = total_samples * maxlen / tb + nreads + 1;
 	return mt > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t) mt;
-}
-
-bool use_v1()
-{
-	if (g.use_v1 < 0) {
-		const char *e = getenv("PRESS_HIP_V1");
-		g.use_v1 = (e && *e == '1') ? 1 : 0;
-	}
-	return g.use_v1 == 1;
 }
 
 uint32_t max_zblocks_of(uint64_t total_samples, uint32_t nreads)
@@ -451,6 +470,7 @@ void ktime_end(int which, hipStream_t s)
 
 extern "C" int press_hip_kernel_timing(int enable)
 {
+	API_LOCK;
 	int rc = ctx_init();
 	if (rc)
 		return rc;
@@ -468,6 +488,7 @@ extern "C" int press_hip_kernel_timing(int enable)
 
 extern "C" int press_hip_kernel_times(int which, float *ms, int max)
 {
+	API_LOCK;
 	if (which < 0 || which > 1 || !kt.made)
 		return 0;
 	int n = kt.n[which] < max ? kt.n[which] : max;
@@ -483,6 +504,7 @@ extern "C" int press_hip_kernel_times(int which, float *ms, int max)
 
 extern "C" int press_hip_set_device(int device)
 {
+	API_LOCK;
 	if (g.ready && device != g.device)
 		press_hip_shutdown();
 	g.device = device;
@@ -491,6 +513,7 @@ extern "C" int press_hip_set_device(int device)
 
 extern "C" int press_hip_set_stream(void *stream)
 {
+	API_LOCK;
 	int rc = ctx_init();
 	if (rc)
 		return rc;
@@ -501,6 +524,7 @@ extern "C" int press_hip_set_stream(void *stream)
 
 extern "C" int press_hip_reset_stream(void)
 {
+	API_LOCK;
 	int rc = ctx_init();
 	if (rc)
 		return rc;
@@ -511,6 +535,7 @@ extern "C" int press_hip_reset_stream(void)
 
 extern "C" void *press_hip_get_stream(void)
 {
+	API_LOCK;
 	if (ctx_init())
 		return nullptr;
 	return (void *) g.stream();
@@ -518,6 +543,7 @@ extern "C" void *press_hip_get_stream(void)
 
 extern "C" int press_hip_synchronize(void)
 {
+	API_LOCK;
 	int rc = ctx_init();
 	if (rc)
 		return rc;
@@ -527,14 +553,15 @@ extern "C" int press_hip_synchronize(void)
 
 extern "C" void press_hip_shutdown(void)
 {
+	API_LOCK;
 	if (!g.ready)
 		return;
 	(void) hipSetDevice(g.device);
 	(void) hipStreamSynchronize(g.own);
-	DevBuf *all[] = { &g.meta, &g.ex_pos, &g.ex_val, &g.low, &g.huff, &g.chunks, &g.gran, &g.ctl, &g.first_chunk, &g.htiles, &g.hgran, &g.cbits, &g.sig, &g.off, &g.nsamp,
-			  &g.arena, &g.arena_off, &g.lens, &g.lens2, &g.outn };
-	for (DevBuf *b : all)
+	for (DevBuf *b = g_bufs; b; b = b->next)
 		b->release();
+	staging_release();
+	g.zs_total = 0;
 	(void) hipStreamDestroy(g.own);
 	g.own = nullptr;
 	g.user = nullptr;
@@ -543,8 +570,23 @@ extern "C" void press_hip_shutdown(void)
 	g.ready = false;
 }
 
+extern "C" uint32_t press_hip_scratch_buffers(uint64_t *bytes)
+{
+	API_LOCK;
+	uint32_t nb = 0;
+	uint64_t b = 0;
+	for (DevBuf *d = g_bufs; d; d = d->next) {
+		nb++;
+		b += d->cap;
+	}
+	if (bytes)
+		*bytes = b;
+	return nb;
+}
+
 extern "C" int press_hip_set_table(const uint32_t len[256], const uint64_t bits[256])
 {
+	API_LOCK;
 	int rc = ctx_init();
 	if (rc)
 		return rc;
@@ -600,15 +642,250 @@ extern "C" uint64_t press_hip_workspace_bytes(int method, uint64_t total_samples
 	return b;
 }
 
+// ------------------------------------------------------------------ host <-> device staging
+//
+// The host-pointer form of the batch calls (device_resident = 0) is what a caller like
+// press/test.c uses: its buffers are ordinary (pageable) memory.  Copies go through two
+// page-locked staging buffers of STAGE_BYTES: while the DMA engine moves one, the host fills
+// (or drains) the other, several threads sharing the memcpy.  Buffers obtained from
+// press_hip_host_alloc() are page-locked themselves and are copied by ONE DMA, no staging.
+// Compressed streams travel densely: a gather kernel packs the slots' contents before the
+// D2H (slots are sized by X_bound, several times their content), and the decoder's input is
+// packed on the host while it is staged.
+
+namespace {
+
+constexpr size_t STAGE_BYTES = 32u << 20;
+constexpr size_t DIRECT_MAX = 256u << 10; // below this a plain hipMemcpyAsync (HIP's own staging) is cheaper
+
+struct Staging {
+	void *buf[2] = { nullptr, nullptr };
+	hipEvent_t ev[2];
+	bool busy[2] = { false, false };
+	bool made = false;
+} stg;
+
+int staging_init()
+{
+	if (stg.made)
+		return 0;
+	for (int k = 0; k < 2; k++) {
+		HIPCHK(hipHostMalloc(&stg.buf[k], STAGE_BYTES, hipHostMallocDefault));
+		HIPCHK(hipEventCreateWithFlags(&stg.ev[k], hipEventDisableTiming));
+	}
+	stg.made = true;
+	return 0;
+}
+
+void staging_release()
+{
+	if (!stg.made)
+		return;
+	for (int k = 0; k < 2; k++) {
+		(void) hipEventDestroy(stg.ev[k]);
+		(void) hipHostFree(stg.buf[k]);
+		stg.buf[k] = nullptr;
+		stg.busy[k] = false;
+	}
+	stg.made = false;
+}
+
+int staging_wait(int k)
+{
+	if (stg.busy[k]) {
+		HIPCHK(hipEventSynchronize(stg.ev[k]));
+		stg.busy[k] = false;
+	}
+	return 0;
+}
+
+bool is_pinned(const void *p)
+{
+	hipPointerAttribute_t a;
+	if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+		(void) hipGetLastError(); // ordinary memory is reported as an error: not one of ours
+		return false;
+	}
+	return a.type == hipMemoryTypeHost;
+}
+
+// memcpy shared by a few threads (one core moves ~10 GB/s, the link 50+)
+void par_memcpy(void *dst, const void *src, size_t n)
+{
+	constexpr size_t MIN_PART = 2u << 20;
+	unsigned nt = (unsigned) (n / MIN_PART);
+	if (nt > 6)
+		nt = 6;
+	if (nt < 2) {
+		memcpy(dst, src, n);
+		return;
+	}
+	const size_t part = (n / nt + 63) & ~(size_t) 63;
+	std::vector<std::thread> th;
+	for (unsigned t = 1; t < nt; t++) {
+		const size_t o = (size_t) t * part;
+		if (o >= n)
+			break;
+		const size_t l = o + part > n ? n - o : part;
+		th.emplace_back([=] { memcpy((char *) dst + o, (const char *) src + o, l); });
+	}
+	memcpy(dst, src, part < n ? part : n);
+	for (auto &t : th)
+		t.join();
+}
+
+// host -> device, asynchronous on s as far as the source allows (returns when src may be reused
+// unless src is page-locked)
+int h2d(void *dst, const void *src, size_t n, hipStream_t s)
+{
+	if (!n)
+		return 0;
+	if (n <= DIRECT_MAX || is_pinned(src)) {
+		HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s));
+		return 0;
+	}
+	int rc = staging_init();
+	if (rc)
+		return rc;
+	int k = 0;
+	for (size_t o = 0; o < n; o += STAGE_BYTES, k ^= 1) {
+		const size_t l = n - o < STAGE_BYTES ? n - o : STAGE_BYTES;
+		if ((rc = staging_wait(k)))
+			return rc;
+		par_memcpy(stg.buf[k], (const char *) src + o, l);
+		HIPCHK(hipMemcpyAsync((char *) dst + o, stg.buf[k], l, hipMemcpyHostToDevice, s));
+		HIPCHK(hipEventRecord(stg.ev[k], s));
+		stg.busy[k] = true;
+	}
+	return 0;
+}
+
+// Pieces of host memory <-> one dense device range, through the staging buffers.
+struct Piece {
+	uint8_t *host;   // where the piece lives on the host
+	uint64_t dense;  // its offset in the dense range
+	uint64_t len;
+};
+
+// pieces must be sorted by `dense` and must not overlap.  TO_DEV: host pieces -> dev[0, total);
+// else dev[0, total) -> host pieces.  Synchronous for the host memory involved.
+template <bool TO_DEV>
+int staged_pieces(uint8_t *dev, uint64_t total, const std::vector<Piece> &pc, hipStream_t s)
+{
+	if (!total)
+		return 0;
+	int rc = staging_init();
+	if (rc)
+		return rc;
+	size_t ip = 0; // first piece that may reach into the current chunk
+	auto host_side = [&](int k, uint64_t o, uint64_t l) { // move the pieces' bytes of chunk [o, o + l)
+		while (ip < pc.size() && pc[ip].dense + pc[ip].len <= o)
+			ip++;
+		for (size_t i = ip; i < pc.size() && pc[i].dense < o + l; i++) {
+			const uint64_t a = pc[i].dense > o ? pc[i].dense : o;
+			const uint64_t b = pc[i].dense + pc[i].len < o + l ? pc[i].dense + pc[i].len : o + l;
+			if (b <= a)
+				continue;
+			uint8_t *h = pc[i].host + (a - pc[i].dense);
+			uint8_t *g = (uint8_t *) stg.buf[k] + (a - o);
+			if (TO_DEV)
+				par_memcpy(g, h, b - a);
+			else
+				par_memcpy(h, g, b - a);
+		}
+	};
+	int k = 0;
+	if (TO_DEV) {
+		for (uint64_t o = 0; o < total; o += STAGE_BYTES, k ^= 1) {
+			const uint64_t l = total - o < STAGE_BYTES ? total - o : STAGE_BYTES;
+			if ((rc = staging_wait(k)))
+				return rc;
+			host_side(k, o, l);
+			HIPCHK(hipMemcpyAsync(dev + o, stg.buf[k], l, hipMemcpyHostToDevice, s));
+			HIPCHK(hipEventRecord(stg.ev[k], s));
+			stg.busy[k] = true;
+		}
+		return 0;
+	}
+	// device -> host: the DMA of chunk i+1 runs while the host drains chunk i
+	uint64_t po = 0, pl = 0;
+	int pk = -1;
+	for (uint64_t o = 0; o < total; o += STAGE_BYTES, k ^= 1) {
+		const uint64_t l = total - o < STAGE_BYTES ? total - o : STAGE_BYTES;
+		if ((rc = staging_wait(k)))
+			return rc;
+		HIPCHK(hipMemcpyAsync(stg.buf[k], dev + o, l, hipMemcpyDeviceToHost, s));
+		HIPCHK(hipEventRecord(stg.ev[k], s));
+		stg.busy[k] = true;
+		if (pk >= 0) {
+			if ((rc = staging_wait(pk)))
+				return rc;
+			host_side(pk, po, pl);
+		}
+		pk = k;
+		po = o;
+		pl = l;
+	}
+	if (pk >= 0) {
+		if ((rc = staging_wait(pk)))
+			return rc;
+		host_side(pk, po, pl);
+	}
+	return 0;
+}
+
+// dense[dense_off[r] ..) = arena[slot_off[r] .. + len[r]) - the streams of a batch packed back to back
+// (16-byte aligned) for ONE copy to the host.  One workgroup per (read, 1/8 of its 4-KiB pieces).
+__global__ __launch_bounds__(256) void k_gather_streams(const uint8_t *arena, const uint64_t *slot_off,
+							const uint64_t *len, const uint64_t *dense_off, uint8_t *dense)
+{
+	const uint32_t r = blockIdx.x;
+	const uint64_t l = len[r];
+	if (l == PRESS_HIP_FAILED || l == 0)
+		return;
+	const uint8_t *src = arena + slot_off[r];
+	uint8_t *dst = dense + dense_off[r];
+	const uint64_t n16 = l / 16;
+	for (uint64_t c = (uint64_t) blockIdx.y * 256 + threadIdx.x; c < n16; c += 256ull * gridDim.y) {
+		uint4 v;
+		__builtin_memcpy(&v, src + 16 * c, 16); // the slot may sit at any byte address
+		*reinterpret_cast<uint4 *>(dst + 16 * c) = v;
+	}
+	if (blockIdx.y == 0 && threadIdx.x < (l & 15))
+		dst[16 * n16 + threadIdx.x] = src[16 * n16 + threadIdx.x];
+}
+
+} // namespace
+
+extern "C" void *press_hip_host_alloc(uint64_t bytes)
+{
+	API_LOCK;
+	if (ctx_init())
+		return nullptr;
+	void *p = nullptr;
+	hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+	if (e != hipSuccess) {
+		fail(PRESS_HIP_EHIP, "hipHostMalloc(%llu): %s", (unsigned long long) bytes, hipGetErrorString(e));
+		return nullptr;
+	}
+	return p;
+}
+
+extern "C" void press_hip_host_free(void *p)
+{
+	API_LOCK;
+	if (p)
+		(void) hipHostFree(p);
+}
+
 // ------------------------------------------------------------------ batch API
 
 static int launch_press(int method, const BatchArgs &a, hipStream_t s)
 {
-	const bool v1 = use_v1();
 	switch (method) {
-	case PRESS_HIP_SVB12:    v1 ? launch_svb_encode(a, false, false, s) : launch_svb_encode_chunked(a, false, false, s); break;
-	case PRESS_HIP_SVB12_ZD: v1 ? launch_svb_encode(a, false, true, s) : launch_svb_encode_chunked(a, false, true, s); break;
-	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_encode(a, true, true, s) : launch_svb_encode_chunked(a, true, true, s); break;
+	case PRESS_HIP_SVB12:    launch_svb_encode_chunked(a, false, false, s); break;
+	case PRESS_HIP_SVB12_ZD: launch_svb_encode_chunked(a, false, true, s); break;
+	case PRESS_HIP_SVB_ZD:   launch_svb_encode_chunked(a, true, true, s); break;
 	case PRESS_HIP_SLOW5_SVB_ZD: launch_svb_encode_chunked(a, true, true, s, true); break;
 	case PRESS_HIP_ZSTD_SVB_ZD:
 	case PRESS_HIP_ZSTD_SVB12_ZD:
@@ -619,8 +896,7 @@ static int launch_press(int method, const BatchArgs &a, hipStream_t s)
 		break;
 	}
 	default:
-		(v1 && !is_rc(method)) ? launch_ex_encode(a, exfmt_of(method), is_shuff(method), s)
-				       : launch_ex_encode_chunked(a, exfmt_of(method), entropy_of(method), s);
+		launch_ex_encode_chunked(a, exfmt_of(method), entropy_of(method), s);
 	}
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess)
@@ -676,11 +952,10 @@ static int zs_host_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t s)
 
 static int launch_depress(int method, const DecodeArgs &a, hipStream_t s)
 {
-	const bool v1 = use_v1();
 	switch (method) {
-	case PRESS_HIP_SVB12:    v1 ? launch_svb_decode(a, false, false, s) : launch_svb_decode_chunked(a, false, false, s); break;
-	case PRESS_HIP_SVB12_ZD: v1 ? launch_svb_decode(a, false, true, s) : launch_svb_decode_chunked(a, false, true, s); break;
-	case PRESS_HIP_SVB_ZD:   v1 ? launch_svb_decode(a, true, true, s) : launch_svb_decode_chunked(a, true, true, s); break;
+	case PRESS_HIP_SVB12:    launch_svb_decode_chunked(a, false, false, s); break;
+	case PRESS_HIP_SVB12_ZD: launch_svb_decode_chunked(a, false, true, s); break;
+	case PRESS_HIP_SVB_ZD:   launch_svb_decode_chunked(a, true, true, s); break;
 	case PRESS_HIP_SLOW5_SVB_ZD: launch_svb_decode_chunked(a, true, true, s, true); break;
 	case PRESS_HIP_ZSTD_SVB_ZD:
 	case PRESS_HIP_ZSTD_SVB12_ZD:
@@ -695,8 +970,7 @@ static int launch_depress(int method, const DecodeArgs &a, hipStream_t s)
 		break;
 	}
 	default:
-		(v1 && !is_rc(method)) ? launch_ex_decode(a, exfmt_of(method), is_shuff(method), s)
-				       : launch_ex_decode_chunked(a, exfmt_of(method), entropy_of(method), s);
+		launch_ex_decode_chunked(a, exfmt_of(method), entropy_of(method), s);
 	}
 	hipError_t e = hipGetLastError();
 	if (e != hipSuccess)
@@ -717,6 +991,7 @@ extern "C" int press_hip_press_batch(int method, const int16_t *sig, const uint6
 				     uint32_t nreads, uint64_t total_samples, uint8_t *out,
 				     const uint64_t *out_off, uint64_t *out_len, int device_resident)
 {
+	API_LOCK;
 	int rc = ctx_init();
 	if (rc)
 		return rc;
@@ -779,11 +1054,11 @@ extern "C" int press_hip_press_batch(int method, const int16_t *sig, const uint6
 	std::vector<uint64_t> rel(nreads + 1);
 	for (uint32_t r = 0; r <= nreads; r++)
 		rel[r] = out_off[r] - a0;
-	HIPCHK(hipMemcpyAsync(g.sig.p, sig, total_samples * 2, hipMemcpyHostToDevice, s));
 	HIPCHK(hipMemcpyAsync(g.off.p, off, (size_t) nreads * 8, hipMemcpyHostToDevice, s));
 	HIPCHK(hipMemcpyAsync(g.nsamp.p, n, (size_t) nreads * 4, hipMemcpyHostToDevice, s));
 	HIPCHK(hipMemcpyAsync(g.arena_off.p, rel.data(), ((size_t) nreads + 1) * 8, hipMemcpyHostToDevice, s));
-	HIPCHK(hipStreamSynchronize(s)); // rel goes out of scope; sig is pageable anyway
+	if ((rc = h2d(g.sig.p, sig, total_samples * 2, s)))
+		return rc;
 	a.sig = (const int16_t *) g.sig.p;
 	a.off = (const uint64_t *) g.off.p;
 	a.nsamp = (const uint32_t *) g.nsamp.p;
@@ -794,12 +1069,39 @@ extern "C" int press_hip_press_batch(int method, const int16_t *sig, const uint6
 		return rc;
 	HIPCHK(hipMemcpyAsync(out_len, g.lens.p, (size_t) nreads * 8, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
+	if (nreads <= 4) { // per-read calls: one small copy each
+		for (uint32_t r = 0; r < nreads; r++) {
+			if (out_len[r] == PRESS_HIP_FAILED || out_len[r] == 0)
+				continue;
+			HIPCHK(hipMemcpyAsync(out + out_off[r], (uint8_t *) g.arena.p + rel[r], out_len[r],
+					      hipMemcpyDeviceToHost, s));
+		}
+		HIPCHK(hipStreamSynchronize(s));
+		return 0;
+	}
+	// the streams packed back to back on the device, ONE pass over the link, scattered into the
+	// caller's slots by the host
+	std::vector<uint64_t> doff(nreads);
+	std::vector<Piece> pc;
+	pc.reserve(nreads);
+	uint64_t dense = 0;
 	for (uint32_t r = 0; r < nreads; r++) {
+		doff[r] = dense;
 		if (out_len[r] == PRESS_HIP_FAILED || out_len[r] == 0)
 			continue;
-		HIPCHK(hipMemcpyAsync(out + out_off[r], (uint8_t *) g.arena.p + rel[r], out_len[r],
-				      hipMemcpyDeviceToHost, s));
+		pc.push_back({ out + out_off[r], dense, out_len[r] });
+		dense += (out_len[r] + 15) & ~15ull;
 	}
+	if (!dense)
+		return 0;
+	if (g.dense.reserve(dense + 64) || g.dense_off.reserve((size_t) nreads * 8))
+		return PRESS_HIP_EHIP;
+	HIPCHK(hipMemcpyAsync(g.dense_off.p, doff.data(), (size_t) nreads * 8, hipMemcpyHostToDevice, s));
+	hipLaunchKernelGGL(k_gather_streams, dim3(nreads, 8), dim3(256), 0, s, (const uint8_t *) g.arena.p,
+			   (const uint64_t *) g.arena_off.p, (const uint64_t *) g.lens.p, (const uint64_t *) g.dense_off.p,
+			   (uint8_t *) g.dense.p);
+	if ((rc = staged_pieces<false>((uint8_t *) g.dense.p, dense, pc, s)))
+		return rc;
 	HIPCHK(hipStreamSynchronize(s));
 	return 0;
 }
@@ -809,6 +1111,7 @@ extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint
 				       const uint64_t *off, const uint32_t *n, uint64_t total_samples,
 				       uint32_t *out_n, int device_resident)
 {
+	API_LOCK;
 	int rc = ctx_init();
 	if (rc)
 		return rc;
@@ -841,11 +1144,6 @@ extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint
 		a.hgran = (uint64_t *) g.hgran.p;
 		a.max_htiles = max_htiles_of(total_samples, nreads);
 	}
-	if (is_shuff(method)) {
-		a.htiles = (HufTile *) g.htiles.p;
-		a.hgran = (uint64_t *) g.hgran.p;
-		a.max_htiles = max_htiles_of(total_samples, nreads);
-	}
 
 	if (device_resident) {
 		if ((uintptr_t) sig & 15)
@@ -860,28 +1158,35 @@ extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint
 		return launch_depress(method, a, s);
 	}
 
-	uint64_t lo = ~0ull, hi = 0;
+	uint64_t dense = 0;
+	std::vector<uint64_t> doff(nreads);
+	std::vector<Piece> pc;
+	pc.reserve(nreads);
 	for (uint32_t r = 0; r < nreads; r++) {
 		if (off[r] & 7)
 			return fail(PRESS_HIP_EARG, "off[%u] is not a multiple of 8 samples", r);
 		if (off[r] + n[r] > total_samples)
 			return fail(PRESS_HIP_EARG, "slot %u ends beyond total_samples", r);
-		lo = in_off[r] < lo ? in_off[r] : lo;
-		hi = in_off[r] + in_len[r] > hi ? in_off[r] + in_len[r] : hi;
+		doff[r] = dense;
+		if (in_len[r])
+			pc.push_back({ const_cast<uint8_t *>(in) + in_off[r], dense, in_len[r] });
+		dense += in_len[r];
 	}
 	if (g.sig.reserve(total_samples * 2 + 64) || g.off.reserve((size_t) nreads * 8) ||
-	    g.nsamp.reserve((size_t) nreads * 4) || g.arena.reserve(hi - lo + 64) || g.arena_off.reserve((size_t) nreads * 8) ||
+	    g.nsamp.reserve((size_t) nreads * 4) || g.arena.reserve(dense + 64) || g.arena_off.reserve((size_t) nreads * 8) ||
 	    g.lens2.reserve((size_t) nreads * 8) || g.outn.reserve((size_t) nreads * 4))
 		return PRESS_HIP_EHIP;
-	std::vector<uint64_t> rel(nreads);
-	for (uint32_t r = 0; r < nreads; r++)
-		rel[r] = in_off[r] - lo;
-	HIPCHK(hipMemcpyAsync(g.arena.p, in + lo, hi - lo, hipMemcpyHostToDevice, s));
-	HIPCHK(hipMemcpyAsync(g.arena_off.p, rel.data(), (size_t) nreads * 8, hipMemcpyHostToDevice, s));
+	HIPCHK(hipMemcpyAsync(g.arena_off.p, doff.data(), (size_t) nreads * 8, hipMemcpyHostToDevice, s));
 	HIPCHK(hipMemcpyAsync(g.lens2.p, in_len, (size_t) nreads * 8, hipMemcpyHostToDevice, s));
 	HIPCHK(hipMemcpyAsync(g.off.p, off, (size_t) nreads * 8, hipMemcpyHostToDevice, s));
 	HIPCHK(hipMemcpyAsync(g.nsamp.p, n, (size_t) nreads * 4, hipMemcpyHostToDevice, s));
-	HIPCHK(hipStreamSynchronize(s));
+	// the streams, packed back to back while they are staged (the caller's slots may be far apart)
+	if (nreads <= 4) {
+		for (const Piece &q : pc)
+			HIPCHK(hipMemcpyAsync((uint8_t *) g.arena.p + q.dense, q.host, q.len, hipMemcpyHostToDevice, s));
+	} else if ((rc = staged_pieces<true>((uint8_t *) g.arena.p, dense, pc, s))) {
+		return rc;
+	}
 	a.in = (const uint8_t *) g.arena.p;
 	a.in_off = (const uint64_t *) g.arena_off.p;
 	a.in_len = (const uint64_t *) g.lens2.p;
@@ -893,12 +1198,53 @@ extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint
 		return rc;
 	HIPCHK(hipMemcpyAsync(out_n, g.outn.p, (size_t) nreads * 4, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
-	for (uint32_t r = 0; r < nreads; r++) {
+	if (nreads <= 4) {
+		for (uint32_t r = 0; r < nreads; r++) {
+			if (out_n[r] == UINT32_MAX || out_n[r] == 0)
+				continue;
+			HIPCHK(hipMemcpyAsync(sig + off[r], (int16_t *) g.sig.p + off[r], (size_t) out_n[r] * 2,
+					      hipMemcpyDeviceToHost, s));
+		}
+		HIPCHK(hipStreamSynchronize(s));
+		return 0;
+	}
+	// only the decoded samples of every read reach the caller's buffer (its padding between the
+	// reads is left alone); reads in ascending slot order for the staged copy
+	std::vector<uint32_t> order(nreads);
+	for (uint32_t r = 0; r < nreads; r++)
+		order[r] = r;
+	bool sorted = true;
+	for (uint32_t r = 1; r < nreads && sorted; r++)
+		sorted = off[r] >= off[r - 1];
+	if (!sorted)
+		std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return off[x] < off[y]; });
+	pc.clear();
+	uint64_t end = 0;
+	for (uint32_t i = 0; i < nreads; i++) {
+		const uint32_t r = order[i];
 		if (out_n[r] == UINT32_MAX || out_n[r] == 0)
 			continue;
-		HIPCHK(hipMemcpyAsync(sig + off[r], (int16_t *) g.sig.p + off[r], (size_t) out_n[r] * 2,
-				      hipMemcpyDeviceToHost, s));
+		if (off[r] * 2 < end)
+			return fail(PRESS_HIP_EARG, "sample slots overlap");
+		pc.push_back({ (uint8_t *) (sig + off[r]), off[r] * 2, (uint64_t) out_n[r] * 2 });
+		end = (off[r] + out_n[r]) * 2;
 	}
+	if (is_pinned(sig)) { // page-locked: the decoded ranges go straight to the caller, one DMA per run of reads
+		size_t i = 0;
+		while (i < pc.size()) {
+			size_t k = i;
+			// reads whose gaps are only the alignment padding travel together (the padding is overwritten)
+			while (k + 1 < pc.size() && pc[k + 1].dense - (pc[k].dense + pc[k].len) < 128)
+				k++;
+			const uint64_t b0 = pc[i].dense, b1 = pc[k].dense + pc[k].len;
+			HIPCHK(hipMemcpyAsync((uint8_t *) sig + b0, (uint8_t *) g.sig.p + b0, b1 - b0, hipMemcpyDeviceToHost, s));
+			i = k + 1;
+		}
+		HIPCHK(hipStreamSynchronize(s));
+		return 0;
+	}
+	if ((rc = staged_pieces<false>((uint8_t *) g.sig.p, end, pc, s)))
+		return rc;
 	HIPCHK(hipStreamSynchronize(s));
 	return 0;
 }
@@ -963,6 +1309,7 @@ void collect_codes(const huffman_node *p, uint64_t code, uint32_t depth, uint32_
 
 int table_from_encoder(SymbolEncoder *se)
 {
+	API_LOCK;
 	uint32_t len[256];
 	uint64_t bits[256];
 	if (!se)
@@ -984,6 +1331,7 @@ int table_from_encoder(SymbolEncoder *se)
 
 int table_from_tree(huffman_node *root)
 {
+	API_LOCK;
 	uint32_t len[256];
 	uint64_t bits[256];
 	if (!root)

@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 // The section's size depends on ALL exceptions of the read, so the input is read twice:
 //   k_ex_scan_chunked  (ticket order + look-back on the exception count): exception list
 //                      (position, value) at its final rank, per-chunk counts, OR of the samples
-//   k_ex_section       (press_kernels.hip): header + section, one lane per read
+//   k_ex_section       (press_sections.hip): header + section, one lane per read
 //   k_low_encode_chunked: the one-byte stream; every chunk knows its offset from the counts,
 //                      so no ordering is needed: one workgroup per chunk, 8-byte stores for
 //                      sub-tiles without exceptions exactly as in k_svb_encode_chunked.
@@ -1209,7 +1209,7 @@ __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 		return;
 	}
 
-	uint32_t kmask = 0, etot = 0, ored32 = 0, zd0 = 0, lbits = 0;
+	uint32_t kmask = 0, etot = 0, ored32 = 0, zd0 = 0, lbits = 0, nocode = 0;
 	uint32_t carry = 0; // the sample in front of the sub-tile
 	if (ws > 0)
 		carry = (uint32_t) (uint16_t) in[ws - 1] << 16;
@@ -1244,6 +1244,8 @@ __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 				for (int h = 0; h < 8; h++) {
 					const uint32_t l = s_len[(zz[h >> 1] >> (16 * (h & 1))) & 0xFFu];
 					lbits += ((lowm >> h) & 1u) ? l : 0u;
+					if (((lowm >> h) & 1u) && l == 0)
+						nocode = 0x80000000u; // a value the table has no code for: the read fails (k_ex_section)
 				}
 			}
 		}
@@ -1256,8 +1258,8 @@ __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 		if (lane == 63)
 			a.cbits[t].q[w] = inc;
 	}
-	if (!REDO) { // OR of the raw samples (qts), one atomic per wave
-		uint32_t o = (ored32 | (ored32 >> 16)) & 0xFFFFu;
+	if (!REDO) { // OR of the raw samples (qts), one atomic per wave; bit 31: a value without a Huffman code
+		uint32_t o = ((ored32 | (ored32 >> 16)) & 0xFFFFu) | (HUFF ? nocode : 0u);
 #pragma unroll
 		for (int dd = 32; dd >= 1; dd >>= 1)
 			o |= (uint32_t) __shfl_xor((int) o, dd, 64);
@@ -2000,7 +2002,7 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, int ent, hipStream_t 
 	ktime_end(0, s);
 }
 
-// exception-split decode: parse + (Huffman) from press_kernels.hip, then the chunked merge
+// exception-split decode: parse + (Huffman) from press_sections.hip / press_huffman.hip, then the chunked merge
 void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, int ent, hipStream_t s)
 {
 	const bool huff = ent != 0; // the one-byte stream comes from a.low (Huffman or range decoder)

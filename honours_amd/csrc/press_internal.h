@@ -1,4 +1,4 @@
-// press_internal.h - shared between the kernels (press_kernels.hip) and the C-ABI
+// press_internal.h - shared between the kernel files (press_*.hip) and the C-ABI
 // host layer (press_abi.hip).  Not installed; the public interface is include/press_hip.h.
 #pragma once
 
@@ -213,21 +213,15 @@ void ktime_begin(int which, hipStream_t s); // which: 0 = press, 1 = depress
 void ktime_end(int which, hipStream_t s);
 void ktime_mute(bool m); // a composite launcher times its own kernel instead of the inner one's
 
-// launchers (press_kernels.hip).  All asynchronous on `s`.
-void launch_svb_encode(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s);      // v1: one workgroup per read
-void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s, bool slow5 = false); // v2: chunks + look-back
+// launchers.  All asynchronous on `s`.
+void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s, bool slow5 = false); // chunks + look-back
 void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s, bool slow5 = false);
 void launch_ex_encode_chunked(const BatchArgs &a, int fmt, int ent, hipStream_t s); // ent: 0 plain, 1 Huffman, 2 range coder
 void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, int ent, hipStream_t s);
-void launch_ex_parse_huff(const DecodeArgs &a, int fmt, int ent, hipStream_t s); // press_kernels.hip
+void launch_ex_parse_huff(const DecodeArgs &a, int fmt, int ent, hipStream_t s); // press_sections.hip
 void launch_huff_decode(const DecodeArgs &a, hipStream_t s);                       // press_huffman.hip
-// pieces of the v1 pipeline reused by the chunked one (press_kernels.hip)
-void launch_ex_section(const BatchArgs &a, int fmt, int ent, hipStream_t s);
+void launch_ex_section(const BatchArgs &a, int fmt, int ent, hipStream_t s);        // press_sections.hip
 void launch_rcs_encode(const BatchArgs &a, hipStream_t s);  // press_rc.hip
 void launch_rcs_decode(const DecodeArgs &a, hipStream_t s);
-void launch_svb_decode(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s);
-// exception-split encode: scan (+ qts redo for ex-zd) -> section -> one-byte / Huffman stream
-void launch_ex_encode(const BatchArgs &a, int fmt, bool huff, hipStream_t s);
-void launch_ex_decode(const DecodeArgs &a, int fmt, bool huff, hipStream_t s);
 
 } // namespace ph

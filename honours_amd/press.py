@@ -75,7 +75,7 @@ HEADER_SYMBOLS = sorted(set(
      "press_hip_blow5_open", "press_hip_blow5_close", "press_hip_blow5_methods", "press_hip_blow5_next",
      "press_hip_blow5_last_error", "press_hip_blow5_next_records", "press_hip_blow5_create",
      "press_hip_blow5_write", "press_hip_blow5_finish",
-     "press_hip_shutdown"]))
+     "press_hip_shutdown", "press_hip_scratch_buffers", "press_hip_host_alloc", "press_hip_host_free"]))
 
 
 class PressError(RuntimeError):
@@ -363,6 +363,80 @@ def depress_batch_host(method, streams, ns):
         raise PressError(last_error())
     return [None if int(k) == 0xFFFFFFFF else sig[int(o): int(o) + int(k)].copy()
             for o, k in zip(off, out_n)]
+
+
+class HostBatch:
+    """A batch in HOST memory laid out once, so that press() / depress() are nothing but the C calls
+    (press_hip_press_batch / press_hip_depress_batch with device_resident = 0): what a C caller that
+    keeps its reads in its own buffers pays - H2D, kernels, D2H - and what bench.py's PCIe-inclusive
+    figure times.  pinned=True takes the buffers from press_hip_host_alloc (page-locked memory:
+    the library then copies by DMA straight from / to them)."""
+
+    def __init__(self, method, reads, pinned=False):
+        lib = load_library()
+        self.lib, self.mid, self.nreads = lib, _mid(method), len(reads)
+        self.pinned = pinned
+        self._held = []
+        self.ns = np.array([len(r) for r in reads], dtype=np.uint32)
+        self.off, self.total = _layout(self.ns)
+        self.sig = self._alloc(self.total + 64, np.int16)
+        self.sig[:] = 0
+        for r, o in zip(reads, self.off):
+            self.sig[int(o): int(o) + len(r)] = r
+        caps = [int(lib.press_hip_bound(self.mid, int(x))) + 1024 for x in self.ns]
+        self.out_off = np.zeros(self.nreads + 1, dtype=np.uint64)
+        self.out_off[1:] = np.cumsum((np.asarray(caps, dtype=np.uint64) + 15) // 16 * 16)
+        self.out = self._alloc(int(self.out_off[-1]) + 64, np.uint8)
+        self.out_len = np.zeros(self.nreads, dtype=np.uint64)
+        self.back = self._alloc(self.total + 64, np.int16)
+        self.out_n = np.zeros(self.nreads, dtype=np.uint32)
+
+    def _alloc(self, count, dtype):
+        nbytes = int(count) * np.dtype(dtype).itemsize
+        if not self.pinned:
+            return np.zeros(count, dtype=dtype)
+        self.lib.press_hip_host_alloc.restype = ctypes.c_void_p
+        self.lib.press_hip_host_alloc.argtypes = [ctypes.c_uint64]
+        p = self.lib.press_hip_host_alloc(nbytes)
+        if not p:
+            raise PressError(last_error())
+        self._held.append(p)
+        buf = (ctypes.c_uint8 * nbytes).from_address(p)
+        return np.frombuffer(buf, dtype=dtype)
+
+    def press(self):
+        rc = self.lib.press_hip_press_batch(self.mid, self.sig.ctypes.data, self.off.ctypes.data,
+                                            self.ns.ctypes.data, self.nreads, self.total, self.out.ctypes.data,
+                                            self.out_off.ctypes.data, self.out_len.ctypes.data, 0)
+        if rc:
+            raise PressError(last_error())
+
+    def streams(self):
+        return [None if int(l) == FAILED else self.out[int(o): int(o) + int(l)].tobytes()
+                for o, l in zip(self.out_off[:-1], self.out_len)]
+
+    def depress(self):
+        """decode the streams press() left in the slots of `out` into `back`"""
+        in_off = np.ascontiguousarray(self.out_off[:-1])
+        rc = self.lib.press_hip_depress_batch(self.mid, self.out.ctypes.data, in_off.ctypes.data,
+                                              self.out_len.ctypes.data, self.nreads, self.back.ctypes.data,
+                                              self.off.ctypes.data, self.ns.ctypes.data, self.total,
+                                              self.out_n.ctypes.data, 0)
+        if rc:
+            raise PressError(last_error())
+
+    def lossless(self):
+        return bool(np.array_equal(self.out_n, self.ns)) and all(
+            np.array_equal(self.back[int(o): int(o) + int(k)], self.sig[int(o): int(o) + int(k)])
+            for o, k in zip(self.off, self.ns))
+
+    def close(self):
+        self.sig = self.out = self.back = None
+        if self._held:
+            self.lib.press_hip_host_free.argtypes = [ctypes.c_void_p]
+            for p in self._held:
+                self.lib.press_hip_host_free(p)
+            self._held = []
 
 
 def kernel_timing(enable=True):

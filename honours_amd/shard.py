@@ -15,11 +15,28 @@ def world_info():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
-def shard_range(total_reads, rank, world):
-    """Contiguous, balanced split of [0, total_reads) - rank's [first, first+count)."""
-    base, rem = divmod(total_reads, world)
-    first = rank * base + min(rank, rem)
-    return first, base + (1 if rank < rem else 0)
+def shard_range(total_reads, rank, world, lengths=None):
+    """Contiguous split of [0, total_reads) - rank's [first, first+count).
+
+    lengths (samples per read): ranks get about equal SAMPLE totals - read lengths are heavy
+    tailed (2 k ... 5.7 M samples, thesis/plots/n-tab.tex), so equal read counts would leave
+    the ranks with unequal work.  Cut k sits where the running sum of the lengths first
+    reaches k/world of the total; every rank computes the same cuts from the same lengths.
+    Without lengths (equal-length reads, BASELINE.json config 5): equal read counts."""
+    if lengths is None:
+        base, rem = divmod(total_reads, world)
+        first = rank * base + min(rank, rem)
+        return first, base + (1 if rank < rem else 0)
+    import numpy as np
+
+    lengths = np.asarray(lengths, dtype=np.int64)
+    assert lengths.size == total_reads
+    cum = np.cumsum(lengths)
+    total = int(cum[-1]) if total_reads else 0
+    # reads [cut[k], cut[k+1]) go to rank k: a read belongs to the rank its MIDPOINT falls into
+    mid = cum - lengths / 2.0
+    cuts = [int(np.searchsorted(mid, total * k / world, side="left")) for k in range(world)] + [total_reads]
+    return cuts[rank], cuts[rank + 1] - cuts[rank]
 
 
 def weak_shard(reads_per_rank, rank):

@@ -194,7 +194,10 @@ enum press_hip_method {
 /* last HIP / library error as text (thread local) */
 const char *press_hip_last_error(void);
 
-/* select the device for this process (default: current device).  One process per GPU. */
+/* select the device for this process (default: current device).  One process per GPU: the
+ * library keeps ONE context (device, stream, scratch).  Calls may come from any host thread -
+ * every entry point re-selects the device for the calling thread and entry points are
+ * serialised by a lock - but two threads cannot run batches concurrently. */
 int press_hip_set_device(int device);
 /* stream (hipStream_t, as void*) the batch calls enqueue on; NULL is HIP's default
  * (null) stream.  Until this is called the library uses a private non-blocking stream;
@@ -205,9 +208,14 @@ void *press_hip_get_stream(void);
 /* block until everything enqueued by batch calls has finished */
 int press_hip_synchronize(void);
 
-/* static Huffman table for the batch API: file in the format of press/NA12878_zd.huffman */
+/* static Huffman table for the batch API: file in the format of press/NA12878_zd.huffman
+ * (huffman.c:549; it may list fewer than 256 symbols) */
 int press_hip_load_table_file(const char *path);
-/* or 256 {length, code bits} pairs; bit k of bits[s] is the k-th emitted bit */
+/* or 256 {length, code bits} pairs; bit k of bits[s] is the k-th emitted bit.
+ * len[s] == 0: symbol s has no code - a read fails (press: PRESS_HIP_FAILED / return 1) only if that
+ * value occurs in it (the reference dereferences a NULL code there, huffman.c:860).
+ * Limit of the device tables: codes of at most 24 bits (huffman.c takes up to 255); longer -> EARG,
+ * and the shuffman_* drop-in symbols return 1 for such a table. */
 int press_hip_set_table(const uint32_t len[256], const uint64_t bits[256]);
 
 /* X_bound of the reference for `method` (what press/test.c allocates) */
@@ -265,6 +273,17 @@ int press_hip_depress_batch(int method, const uint8_t *in, const uint64_t *in_of
  *            stream decides (press.c:1901).  Content checksums are not verified.
  */
 
+/*
+ * Host buffers (device_resident == 0).  Ordinary (pageable) memory is copied through two page-locked
+ * staging buffers of 32 MiB (the DMA of one overlaps the host's memcpy into / out of the other);
+ * compressed streams cross the link packed back to back, whatever the slots' sizes.  Buffers from
+ * press_hip_host_alloc() are page-locked: `sig` is then copied by ONE DMA in press, and in depress the
+ * decoded samples are written straight into it (the alignment padding between reads is overwritten).
+ * Both calls return when the caller's buffers are complete.
+ */
+void *press_hip_host_alloc(uint64_t bytes); /* hipHostMalloc; NULL on failure */
+void press_hip_host_free(void *p);
+
 /* bytes of device scratch the two calls above keep for a batch of this shape (informational) */
 uint64_t press_hip_workspace_bytes(int method, uint64_t total_samples, uint32_t nreads);
 
@@ -275,8 +294,12 @@ uint64_t press_hip_workspace_bytes(int method, uint64_t total_samples, uint32_t 
 int press_hip_kernel_timing(int enable);
 int press_hip_kernel_times(int which, float *ms, int max);
 
-/* release every device and host resource held by the library */
+/* release every device and host resource held by the library (all scratch buffers, the device
+ * copy of the Huffman table, the private stream).  press_hip_set_device(other) goes through it. */
 void press_hip_shutdown(void);
+/* number of scratch buffers the library keeps; *bytes (may be NULL) = device bytes they hold now
+ * (0 after press_hip_shutdown) */
+uint32_t press_hip_scratch_buffers(uint64_t *bytes);
 
 /* ======================================================================= (3) BLOW5 files (host) */
 

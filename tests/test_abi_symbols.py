@@ -72,3 +72,20 @@ def test_no_gpu_fails_loudly(lib):
     ret, out = press.press("hasgam_vbsse21_zdq", np.arange(100, dtype=np.int16))
     assert ret != 0 and out == b""
     assert "HIP" in press.last_error() or "hip" in press.last_error()
+
+
+def test_scratch_registry_without_gpu():
+    """every scratch buffer of the library is on the list press_hip_shutdown() walks (a buffer cannot be
+    forgotten: it links itself in when it is constructed); nothing is allocated before the first call"""
+    import ctypes
+
+    lib = press.load_library()
+    lib.press_hip_scratch_buffers.restype = ctypes.c_uint32
+    lib.press_hip_scratch_buffers.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    nbytes = ctypes.c_uint64(1)
+    nbuf = lib.press_hip_scratch_buffers(ctypes.byref(nbytes))
+    assert nbuf >= 45  # 12 shared + 21 zstd + 10 host staging + ...
+    import torch
+    if not torch.cuda.is_available():
+        assert nbytes.value == 0
+    lib.press_hip_shutdown()  # harmless without a context

@@ -222,9 +222,38 @@ def test_batch_host_matches_per_read(oracle, m):
         assert b is not None and np.array_equal(b, r), (m, len(r))
 
 
-def test_batch_device_resident_roundtrip(oracle):
-    """device-resident batch (the bench path): torch tensors, torch's stream; compressed
-    size total equals the oracle's; lossless round trip on the device"""
+def _device_batch(m, sig_al, starts, n_np, dev):
+    """press_batch + depress_batch with device-resident tensors on torch's stream (what bench.py times)
+    -> (streams as bytes per read, decoded tensor, decoded counts)"""
+    import torch
+
+    nreads = len(n_np)
+    d_off = torch.from_numpy(starts[:-1].astype(np.int64)).to(dev)
+    d_n = torch.from_numpy(n_np.astype(np.int32)).to(dev)
+    caps = np.array([press.bound(m, int(x)) + 64 for x in n_np], dtype=np.int64)
+    caps = (caps + 127) // 128 * 128
+    out_off = np.concatenate([[0], np.cumsum(caps)])
+    d_out = torch.empty(int(out_off[-1]) + 64, dtype=torch.uint8, device=dev)
+    d_out_off = torch.from_numpy(out_off).to(dev)
+    d_len = torch.zeros(nreads, dtype=torch.int64, device=dev)
+    press.press_batch(m, sig_al, d_off, d_n, d_out, d_out_off, d_len)
+    torch.cuda.synchronize()
+    lens = d_len.cpu().numpy()
+    assert (lens > 0).all() and (lens <= caps).all(), m
+    arena = d_out.cpu().numpy()
+    streams = [arena[int(out_off[k]):int(out_off[k]) + int(lens[k])].tobytes() for k in range(nreads)]
+    d_back = torch.zeros_like(sig_al)
+    d_outn = torch.zeros(nreads, dtype=torch.int32, device=dev)
+    press.depress_batch(m, d_out, d_out_off[:-1].contiguous(), d_len, d_back, d_off, d_n, d_outn)
+    torch.cuda.synchronize()
+    return streams, d_back, d_outn.cpu().numpy()
+
+
+@pytest.mark.parametrize("m", sorted(press.METHODS))
+def test_batch_device_resident_roundtrip(oracle, m):
+    """device-resident batch (the path bench.py times), EVERY batch method, every read: the stream
+    of each read equals the oracle's (zstd frames, whose bytes are not pinned: the oracle's decoder -
+    libzstd + the inner codec - reads them back), and the device decodes its own batch losslessly"""
     import torch
 
     dev = torch.device("cuda:0")
@@ -233,34 +262,105 @@ def test_batch_device_resident_roundtrip(oracle):
     sig_al, starts, n_np = synth.synth_batch_torch(3, 0, nreads, dev, align=8)
     total = int(starts[-1])
     sig_al = torch.cat([sig_al, torch.zeros(64, dtype=torch.int16, device=dev)])
-    d_off = torch.from_numpy(starts[:-1].astype(np.int64)).to(dev)
-    d_n = torch.from_numpy(n_np.astype(np.int32)).to(dev)
-    off = starts
     host = sig_al.cpu().numpy()
-    for m in ("svb12_zd", "svb_zd", "vbe21_zd", "hasgam_vbsse21_zdq", "shuffman_vbe21_zd"):
-        caps = np.array([press.bound(m, int(x)) + 64 for x in n_np], dtype=np.int64)
-        caps = (caps + 127) // 128 * 128
-        out_off = np.concatenate([[0], np.cumsum(caps)])
-        d_out = torch.empty(int(out_off[-1]) + 64, dtype=torch.uint8, device=dev)
-        d_out_off = torch.from_numpy(out_off).to(dev)
-        d_len = torch.zeros(nreads, dtype=torch.int64, device=dev)
-        press.press_batch(m, sig_al, d_off, d_n, d_out, d_out_off, d_len)
-        torch.cuda.synchronize()
-        lens = d_len.cpu().numpy()
-        assert (lens > 0).all(), m
-        want = 0
-        for k in (0, 1, nreads - 1):
-            ret, w = oracle.press(m, host[int(off[k]):int(off[k]) + int(n_np[k])])
-            assert ret == 0
-            got = d_out[int(out_off[k]):int(out_off[k]) + int(lens[k])].cpu().numpy().tobytes()
-            assert got == w, (m, k)
-        # decode on the device
-        d_back = torch.zeros_like(sig_al)
-        d_outn = torch.zeros(nreads, dtype=torch.int32, device=dev)
-        press.depress_batch(m, d_out, d_out_off[:-1].contiguous(), d_len, d_back, d_off, d_n, d_outn)
-        torch.cuda.synchronize()
-        assert np.array_equal(d_outn.cpu().numpy(), n_np.astype(np.int32)), m
-        assert torch.equal(d_back[:total], sig_al[:total]), m
+    streams, d_back, outn = _device_batch(m, sig_al, starts, n_np, dev)
+    for k in range(nreads):
+        s = host[int(starts[k]):int(starts[k]) + int(n_np[k])]
+        if m in DET:
+            ret, w = oracle.press(m, s)
+            assert ret == 0 and streams[k] == w, (m, k, len(streams[k]), len(w))
+        else:
+            ret, back = oracle.depress(m, streams[k], s.size)
+            assert ret == 0 and np.array_equal(back, s), (m, k)
+    assert np.array_equal(outn, n_np.astype(np.int32)), m
+    assert torch.equal(d_back[:total], sig_al[:total]), m
+
+
+@pytest.mark.parametrize("m", ["shuffman_vbe21_zd", "svb12_zd", "zstd_svb_zd", "hasgam_vbsse21_zdq"])
+def test_config5_shape(oracle, m):
+    """BASELINE.json config 5's shape: fixed 200 000-sample reads (what bench.py --gpus N > 1 runs on every
+    rank), device resident; a few dozen reads against the oracle"""
+    import torch
+
+    dev = torch.device("cuda:0")
+    press.use_torch_stream()
+    nreads = 24
+    sig_al, starts, n_np = synth.synth_batch_torch(20261004, 4096, nreads, dev, fixed_len=200000, align=64)
+    assert (n_np == 200000).all()
+    total = int(starts[-1])
+    sig_al = torch.cat([sig_al, torch.zeros(64, dtype=torch.int16, device=dev)])
+    host = sig_al.cpu().numpy()
+    streams, d_back, outn = _device_batch(m, sig_al, starts, n_np, dev)
+    for k in range(nreads):
+        s = host[int(starts[k]):int(starts[k]) + 200000]
+        # the generator is counter based: the device's reads are the numpy generator's
+        if k < 2:
+            assert np.array_equal(s, synth.synth_read(20261004, 4096 + k, 200000,
+                                                      synth.read_lengths(20261004, 4096 + k, 1, 200000)[1][0]))
+        if m in DET:
+            ret, w = oracle.press(m, s)
+            assert ret == 0 and streams[k] == w, (m, k)
+        else:
+            ret, back = oracle.depress(m, streams[k], s.size)
+            assert ret == 0 and np.array_equal(back, s), (m, k)
+    assert (outn == 200000).all()
+    assert torch.equal(d_back[:total], sig_al[:total]), m
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("m", ["svb12_zd", "shuffman_vbe21_zd", "zstd_svb_zd", "vbsse21_zd"])
+def test_host_batch_staging(oracle, m, pinned):
+    """host buffers through the batch API (device_resident = 0): pageable memory goes through the
+    page-locked staging buffers (several 32-MiB chunks here), press_hip_host_alloc memory by direct DMA;
+    streams land in the caller's slots, samples in the caller's layout, padding untouched (pageable)"""
+    sig, off = synth.synth_batch(13, 200, 300)  # ~34 M samples: 68 MB in, > 2 staging chunks
+    reads = [sig[int(off[k]):int(off[k + 1])] for k in range(300)]
+    reads += [reads[0][:5], reads[1][:2049], reads[2][:9]]
+    hb = press.HostBatch(m, reads, pinned=pinned)
+    hb.back[:] = 0x5A5A
+    hb.press()
+    st = hb.streams()
+    for k in (0, 1, 2, 150, 299, 300, 301, 302):
+        if m in DET:
+            ret, w = oracle.press(m, reads[k])
+            assert ret == 0 and st[k] == w, (m, k)
+        else:
+            ret, back = oracle.depress(m, st[k], len(reads[k]))
+            assert ret == 0 and np.array_equal(back, reads[k]), (m, k)
+    hb.depress()
+    assert hb.lossless(), m
+    if not pinned:
+        for o, k, nxt in zip(hb.off[:-1], hb.ns[:-1], hb.off[1:]):
+            assert (hb.back[int(o) + int(k):int(nxt)] == 0x5A5A).all()
+    hb.close()
+
+
+def test_shutdown_releases_every_buffer(oracle):
+    """press_hip_shutdown() must free ALL scratch (the zstd buffers were forgotten) so that a
+    later press_hip_set_device() cannot leave pointers of the old device behind"""
+    import ctypes
+
+    lib = press.load_library()
+    lib.press_hip_scratch_buffers.restype = ctypes.c_uint32
+    lib.press_hip_scratch_buffers.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+    sig, off = synth.synth_batch(2, 0, 6)
+    reads = [sig[int(off[k]):int(off[k + 1])] for k in range(6)]
+    for m in ("zstd_svb_zd", "shuffman_vbe21_zd", "rc_vbe21_zd"):
+        st = press.press_batch_host(m, reads)
+        back = press.depress_batch_host(m, st, [len(r) for r in reads])
+        assert all(np.array_equal(b, r) for b, r in zip(back, reads))
+    nbytes = ctypes.c_uint64()
+    nbuf = lib.press_hip_scratch_buffers(ctypes.byref(nbytes))
+    assert nbuf >= 45 and nbytes.value > 0
+    lib.press_hip_shutdown()
+    assert lib.press_hip_scratch_buffers(ctypes.byref(nbytes)) == nbuf and nbytes.value == 0
+    # the library comes back by itself (the table has to be loaded again)
+    press.load_table()
+    st = press.press_batch_host("zstd_svb_zd", reads)
+    back = press.depress_batch_host("zstd_svb_zd", st, [len(r) for r in reads])
+    assert all(np.array_equal(b, r) for b, r in zip(back, reads))
+    ret, got = press.press("shuffman_vbe21_zd", reads[0])
+    assert ret == 0 and got == oracle.press("shuffman_vbe21_zd", reads[0])[1]
 
 
 # ---------------------------------------------------------------- static Huffman: tables other than NA12878
@@ -322,6 +422,41 @@ def test_huffman_other_tables(oracle, tmp_path, name):
             for m in ("shuffman_vbe21_zd", "shuffman_vbsse21_zd"):
                 if shuff_ok(m, sig):
                     check_read(oracle, m, sig)
+    finally:
+        oracle.load_table()
+        press.use_table()
+
+
+def test_huffman_table_with_fewer_symbols(oracle, tmp_path):
+    """a table file that lists fewer than 256 symbols (huffman.c:549 takes count <= 256): reads that do
+    not use the missing values code exactly as with the oracle; a read that does fails (the reference
+    dereferences a NULL code there, huffman.c:860) - and only that read"""
+    lens = [4] * 8 + [5] * 16  # 24 symbols, Kraft sum = 1
+    order = sorted(range(24), key=lambda s: (lens[s], s))
+    code, prev, bits = 0, lens[order[0]], [0] * 24
+    for sy in order:
+        code <<= lens[sy] - prev
+        prev = lens[sy]
+        bits[sy] = int(format(code, "0%db" % lens[sy])[::-1], 2)
+        code += 1
+    blob = bytearray((24).to_bytes(4, "big") + bytes(4))
+    for sy in range(24):
+        blob += bytes([sy, lens[sy]]) + bits[sy].to_bytes((lens[sy] + 7) // 8, "little")
+    path = str(tmp_path / "partial.huffman")
+    open(path, "wb").write(bytes(blob))
+    rng = np.random.default_rng(4)
+    try:
+        oracle.load_table(path)
+        press.use_table(path)
+        good = np.cumsum(rng.integers(-11, 12, size=70000)).astype(np.int16)   # zig-zag deltas 0..22
+        bad = good.copy()
+        bad[40000:] += 100  # one delta of 100: zig-zag 200, no code
+        for m in ("shuffman_vbe21_zd", "shuffman_vbbe21_zd"):
+            check_read(oracle, m, good)
+            assert oracle.press(m, bad)[0] != 0
+            assert press.press(m, bad)[0] != 0
+            st = press.press_batch_host(m, [good, bad, good[:3000]])
+            assert st[1] is None and st[0] == oracle.press(m, good)[1] and st[2] == oracle.press(m, good[:3000])[1]
     finally:
         oracle.load_table()
         press.use_table()

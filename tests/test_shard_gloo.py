@@ -81,3 +81,28 @@ def test_shard_range_balanced():
             for a, b in zip(parts, parts[1:]):
                 assert a[0] + a[1] == b[0]
             assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def test_shard_range_by_samples():
+    """contiguous ranges of the read index with about equal sample totals - read
+    lengths are heavy tailed, so the cut is placed on the running sum of the lengths."""
+    from honours_amd import shard, synth
+
+    n, _ = synth.read_lengths(5, 0, 4000)
+    for world in (1, 2, 3, 4, 8):
+        parts = [shard.shard_range(n.size, r, world, lengths=n) for r in range(world)]
+        assert parts[0][0] == 0 and sum(c for _, c in parts) == n.size
+        for a, b in zip(parts, parts[1:]):
+            assert a[0] + a[1] == b[0]
+        tot = [int(n[f:f + c].sum()) for f, c in parts]
+        # no rank is further from its fair share than one (longest) read
+        assert max(abs(t - int(n.sum()) / world) for t in tot) <= int(n.max())
+        # and by read COUNT the same split would be visibly unequal in samples
+    # degenerate inputs
+    assert shard.shard_range(0, 0, 2, lengths=[]) == (0, 0)
+    assert shard.shard_range(1, 0, 2, lengths=[10]) in ((0, 1), (0, 0))
+    assert sum(shard.shard_range(1, r, 2, lengths=[10])[1] for r in range(2)) == 1
+    # one giant read next to small ones: it gets a rank of its own
+    lens = [5_000_000] + [10_000] * 500
+    p = [shard.shard_range(len(lens), r, 2, lengths=lens) for r in range(2)]
+    assert p[0] == (0, 1) and p[1] == (1, 500)
