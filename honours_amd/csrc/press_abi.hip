@@ -91,7 +91,7 @@ struct Ctx {
 	hipStream_t user = nullptr;
 	bool use_user = false;
 	// scratch shared by both modes
-	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, hgran, cbits;
+	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, hrec, hlist, htbase, hread, cbits;
 	DevBuf ztmp, zoff, zoff4, zlen, zhist, ztab, zfirst, zblk, zsbits, zbpos, zbflag, zkcnt, zkbase, zrd, znb, zn, zdcopy, zdhuf, zdunit, zdtree, zdctl; // zstd frames
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn, dense, dense_off;
@@ -301,6 +301,22 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 			h.lut32[i] = v;
 		}
 	}
+	// every whole code that fits in the first HUF_LUT_BITS bits, lengths only (k_huf_sync)
+	for (uint32_t i = 0; i < (1u << HUF_LUT_BITS); i++) {
+		uint32_t pos = 0, n = 0, len1 = 0;
+		for (;;) {
+			const uint16_t e1 = h.lut[i >> pos]; // the upper bits are zeros, not stream bits:
+			if (e1 == 0xFFFFu || (e1 & 0x8000u) || pos + (uint32_t) (e1 >> 8) > (uint32_t) HUF_LUT_BITS)
+				break; // only a code that fits counts
+			if (!n)
+				len1 = e1 >> 8;
+			pos += e1 >> 8;
+			n++;
+			if (pos == (uint32_t) HUF_LUT_BITS || n == 15)
+				break;
+		}
+		h.mlut[i] = n ? (uint16_t) (pos | (n << 4) | (len1 << 8)) : (uint16_t) 0xFFFFu;
+	}
 	if (!ncoded)
 		return fail(PRESS_HIP_EARG, "Huffman table: no symbol has a code");
 	h.minlen = 64;
@@ -338,9 +354,21 @@ uint32_t max_htiles_of(uint64_t total_samples, uint32_t nreads)
 		minlen = g.tlen[s] < minlen ? g.tlen[s] : minlen;
 		maxlen = g.tlen[s] > maxlen ? g.tlen[s] : maxlen;
 	}
-	const uint64_t tb = (uint64_t) HUF_HT * (minlen >= 4 ? 128u : minlen >= 2 ? 64u : 32u);
+	const uint64_t tb = (uint64_t) HUF_HT * (minlen >= 4 ? 256u : minlen >= 2 ? 128u : 64u);
 	const uint64_t mt = total_samples * maxlen / tb + nreads + 1;
-	return mt > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t) mt;
+	return mt > 0xFFFFFFull ? 0xFFFFFFu : (uint32_t) mt; // (subsequence ids are 32-bit: 2^24 tiles x 256)
+}
+
+// broken links a repair round can list (3 % of the subsequences on signal data; what does not fit
+// is left to the serial pass)
+size_t hlist_cap_of(size_t max_htiles) { return max_htiles * HUF_HT / 4 + 1024; }
+uint32_t table_minlen()
+{
+	uint32_t minlen = 64;
+	for (int s = 0; s < 256; s++)
+		if (g.tlen[s] && g.tlen[s] < minlen)
+			minlen = g.tlen[s];
+	return minlen;
 }
 
 uint32_t max_zblocks_of(uint64_t total_samples, uint32_t nreads)
@@ -430,7 +458,8 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 		if (decode && is_shuff(method)) {
 			const size_t mt = max_htiles_of(total_samples, nreads);
 			if (g.low.reserve(total_samples + 64) || g.htiles.reserve(mt * sizeof(HufTile)) ||
-			    g.hgran.reserve(mt * 8))
+			    g.hrec.reserve(mt * HUF_HT * 4) || g.hlist.reserve(hlist_cap_of(mt) * 4) ||
+			    g.htbase.reserve(mt * 4) || g.hread.reserve(((size_t) nreads + 1) * 8))
 				return PRESS_HIP_EHIP;
 		}
 	}
@@ -1141,8 +1170,13 @@ extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint
 	a.max_chunks = max_chunks_of(total_samples, nreads);
 	if (is_shuff(method)) {
 		a.htiles = (HufTile *) g.htiles.p;
-		a.hgran = (uint64_t *) g.hgran.p;
+		a.hrec = (uint32_t *) g.hrec.p;
+		a.hlist = (uint32_t *) g.hlist.p;
+		a.htbase = (uint32_t *) g.htbase.p;
+		a.hread = (uint32_t *) g.hread.p;
 		a.max_htiles = max_htiles_of(total_samples, nreads);
+		a.hlist_cap = (uint32_t) hlist_cap_of(a.max_htiles);
+		a.huf_minlen = table_minlen();
 	}
 
 	if (device_resident) {

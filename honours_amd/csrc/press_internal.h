@@ -47,14 +47,16 @@ struct HuffDev {
 	// (len1 + len2) << 21 | ncodes << 26, ncodes = 2 when two whole codes fit in HUF_LUT_BITS
 	// bits, else 1 (then the len1 + len2 field repeats len1); HUF_LONG | id for a long code's
 	// prefix; 0xFFFFFFFF: walk the trie
-	uint32_t lut32[1 << HUF_LUT_BITS];
+	alignas(16) uint32_t lut32[1 << HUF_LUT_BITS];
+	// length-only first level for k_huf_sync: every whole code that fits in HUF_LUT_BITS bits at once:
+	// total bits | codes << 4 | bits of the first code << 8; 0xFFFF: the first code is longer (or none)
+	alignas(16) uint16_t mlut[1 << HUF_LUT_BITS];
 };
 constexpr uint32_t HUF_LONG = 1u << 30;
 
 // parallel Huffman decode (press_huffman.hip): tiles of HUF_HT subsequences, one workgroup each
-constexpr int HUF_HT = 512;     // threads per workgroup = subsequences per tile
-constexpr int HUF_HSYM = 32;    // most codes that can start in one subsequence
-constexpr uint32_t HUF_GRID = 768; // persistent workgroups (3 per CU: 53 KB of LDS each)
+constexpr int HUF_HT = 256;        // threads per workgroup = subsequences per tile
+constexpr int HUF_FIX_ROUNDS = 3;  // parallel repair rounds before the serial pass of k_huf_chain
 
 // ---- chunked (v2) svb kernels: a read is cut into chunks of CHUNK samples, one workgroup
 // per chunk; chunks of a read are chained by a decoupled look-back over 8-byte granules.
@@ -140,8 +142,13 @@ struct DecodeArgs {
 	uint32_t max_chunks;
 	// Huffman tiles (press_huffman.hip)
 	HufTile *htiles;          // [max_htiles]
-	uint64_t *hgran;          // [max_htiles] look-back granules
+	uint32_t *hrec;           // [max_htiles * HUF_HT] one record per subsequence
+	uint32_t *hlist;          // [hlist_cap] broken links of a repair round
+	uint32_t *htbase;         // [max_htiles] codes of the read in front of the tile
+	uint32_t *hread;          // [2 * nreads] first tile, number of tiles of read r
 	uint32_t max_htiles;
+	uint32_t hlist_cap;
+	uint32_t huf_minlen;      // shortest code of the table (selects the subsequence size on the host)
 };
 
 // zstd frames on the device (press_zstd.hip, zs_table.h): scratch of one batch
@@ -219,7 +226,7 @@ void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipSt
 void launch_ex_encode_chunked(const BatchArgs &a, int fmt, int ent, hipStream_t s); // ent: 0 plain, 1 Huffman, 2 range coder
 void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, int ent, hipStream_t s);
 void launch_ex_parse_huff(const DecodeArgs &a, int fmt, int ent, hipStream_t s); // press_sections.hip
-void launch_huff_decode(const DecodeArgs &a, hipStream_t s);                       // press_huffman.hip
+void launch_huff_decode(const DecodeArgs &a, uint32_t minlen, hipStream_t s);      // press_huffman.hip
 void launch_ex_section(const BatchArgs &a, int fmt, int ent, hipStream_t s);        // press_sections.hip
 void launch_rcs_encode(const BatchArgs &a, hipStream_t s);  // press_rc.hip
 void launch_rcs_decode(const DecodeArgs &a, hipStream_t s);

@@ -467,7 +467,7 @@ void launch_ex_parse_huff(const DecodeArgs &a, int fmt, int ent, hipStream_t s)
 		if (ent == 2)
 			launch_rcs_decode(a, s);
 		else
-			launch_huff_decode(a, s);
+			launch_huff_decode(a, a.huf_minlen, s);
 		ktime_end(1, s);
 	}
 }
