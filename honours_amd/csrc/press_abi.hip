@@ -91,7 +91,7 @@ struct Ctx {
 	hipStream_t user = nullptr;
 	bool use_user = false;
 	// scratch shared by both modes
-	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, hrec, hlist, htbase, hread, cbits;
+	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, htrec, hrec, hlist, hread, cbits;
 	DevBuf ztmp, zoff, zoff4, zlen, zhist, ztab, zfirst, zblk, zsbits, zbpos, zbflag, zkcnt, zkbase, zrd, znb, zn, zdcopy, zdhuf, zdunit, zdtree, zdctl; // zstd frames
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn, dense, dense_off;
@@ -264,13 +264,19 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 			if (id_of[pfx] >= 0 && len[s] - HUF_LUT_BITS > depth[id_of[pfx]])
 				depth[id_of[pfx]] = len[s] - HUF_LUT_BITS;
 		}
-		for (int id = 0; id < nid; id++) {
-			if (used + (1u << depth[id]) > (uint32_t) HUF_L2_ENTRIES)
-				continue; // does not fit: this prefix keeps 0xFFFF and walks the trie
-			h.l2off[id] = (uint16_t) used;
-			h.l2bits[id] = (uint8_t) depth[id];
-			h.lut[prefix_of[id]] = (uint16_t) (0x8000u | (uint32_t) id);
-			used += 1u << depth[id];
+		// deepest first: every table then starts at a multiple of its own size (the first-level
+		// entries of the parallel decoder keep offset / 2 in 11 bits)
+		for (uint32_t d = 32; d >= 1; d--) {
+			for (int id = 0; id < nid; id++) {
+				if (depth[id] != d)
+					continue;
+				if (d > 12 || used + (1u << d) > (uint32_t) HUF_L2_ENTRIES)
+					continue; // does not fit: this prefix keeps 0xFFFF and walks the trie
+				h.l2off[id] = (uint16_t) used;
+				h.l2bits[id] = (uint8_t) d;
+				h.lut[prefix_of[id]] = (uint16_t) (0x8000u | (uint32_t) id);
+				used += 1u << d;
+			}
 		}
 		for (int s = 0; s < 256; s++) {
 			if (len[s] <= (uint32_t) HUF_LUT_BITS)
@@ -283,21 +289,24 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 			for (uint32_t i = rest; i < (1u << depth[id]); i += 1u << rl)
 				h.lut2[h.l2off[id] + i] = (uint16_t) (s | (len[s] << 8));
 		}
+		for (int i = 0; i < HUF_L2_ENTRIES; i++)
+			h.l2len[i] = h.lut2[i] == 0xFFFFu ? (uint8_t) 0xFF : (uint8_t) (h.lut2[i] >> 8);
 	}
 	// two-symbol table
 	for (uint32_t i = 0; i < (1u << HUF_LUT_BITS); i++) {
 		const uint16_t e1 = h.lut[i];
 		if (e1 == 0xFFFFu) {
 			h.lut32[i] = 0xFFFFFFFFu;
-		} else if (e1 & 0x8000u) {
-			h.lut32[i] = HUF_LONG | (e1 & 0xFFu);
+		} else if (e1 & 0x8000u) { // a long code's prefix: where its second-level table sits
+			const uint32_t id = e1 & 0xFFu;
+			h.lut32[i] = HUF_LONG | ((uint32_t) h.l2bits[id] << 12) | h.l2off[id];
 		} else {
 			const uint32_t s1 = e1 & 0xFFu, l1 = e1 >> 8;
-			uint32_t v = s1 | (l1 << 16) | (l1 << 21) | (1u << 26);
+			uint32_t v = s1 | (l1 << 8) | (l1 << 24);
 			const uint32_t rest = (uint32_t) HUF_LUT_BITS - l1;
 			const uint16_t e2 = h.lut[i >> l1]; // the upper bits are zeros, not stream bits:
 			if (e2 != 0xFFFFu && !(e2 & 0x8000u) && (uint32_t) (e2 >> 8) <= rest) // only a code that fits counts
-				v = s1 | ((uint32_t) (e2 & 0xFFu) << 8) | (l1 << 16) | ((l1 + (e2 >> 8)) << 21) | (2u << 26);
+				v = s1 | ((l1 + (e2 >> 8)) << 8) | ((uint32_t) (e2 & 0xFFu) << 16) | (l1 << 24) | HUF_TWO;
 			h.lut32[i] = v;
 		}
 	}
@@ -315,7 +324,13 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 			if (pos == (uint32_t) HUF_LUT_BITS || n == 15)
 				break;
 		}
-		h.mlut[i] = n ? (uint16_t) (pos | (n << 4) | (len1 << 8)) : (uint16_t) 0xFFFFu;
+		const uint16_t e0 = h.lut[i];
+		if (n)
+			h.mlut[i] = (uint16_t) (pos | (n << 4) | (len1 << 8));
+		else if (e0 != 0xFFFFu && (e0 & 0x8000u)) // long code: second-level table of lengths (HUF_MLONG)
+			h.mlut[i] = (uint16_t) (0x8000u | ((uint32_t) h.l2bits[e0 & 0xFFu] << 11) | (h.l2off[e0 & 0xFFu] >> 1));
+		else
+			h.mlut[i] = (uint16_t) 0xFFFFu;
 	}
 	if (!ncoded)
 		return fail(PRESS_HIP_EARG, "Huffman table: no symbol has a code");
@@ -356,12 +371,12 @@ uint32_t max_htiles_of(uint64_t total_samples, uint32_t nreads)
 	}
 	const uint64_t tb = (uint64_t) HUF_HT * (minlen >= 4 ? 256u : minlen >= 2 ? 128u : 64u);
 	const uint64_t mt = total_samples * maxlen / tb + nreads + 1;
-	return mt > 0xFFFFFFull ? 0xFFFFFFu : (uint32_t) mt; // (subsequence ids are 32-bit: 2^24 tiles x 256)
+	return mt > 0xFFFFFFull ? 0xFFFFFFu : (uint32_t) mt;
 }
 
 // broken links a repair round can list (3 % of the subsequences on signal data; what does not fit
 // is left to the serial pass)
-size_t hlist_cap_of(size_t max_htiles) { return max_htiles * HUF_HT / 4 + 1024; }
+size_t hlist_cap_of(size_t max_htiles) { return max_htiles / 2 + 1024; }
 uint32_t table_minlen()
 {
 	uint32_t minlen = 64;
@@ -458,8 +473,8 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 		if (decode && is_shuff(method)) {
 			const size_t mt = max_htiles_of(total_samples, nreads);
 			if (g.low.reserve(total_samples + 64) || g.htiles.reserve(mt * sizeof(HufTile)) ||
-			    g.hrec.reserve(mt * HUF_HT * 4) || g.hlist.reserve(hlist_cap_of(mt) * 4) ||
-			    g.htbase.reserve(mt * 4) || g.hread.reserve(((size_t) nreads + 1) * 8))
+			    g.htrec.reserve(mt * sizeof(HufTRec)) || g.hrec.reserve(mt * HUF_HT * 4) ||
+			    g.hlist.reserve(hlist_cap_of(mt) * 8) || g.hread.reserve(((size_t) nreads + 1) * 8))
 				return PRESS_HIP_EHIP;
 		}
 	}
@@ -1170,9 +1185,9 @@ extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint
 	a.max_chunks = max_chunks_of(total_samples, nreads);
 	if (is_shuff(method)) {
 		a.htiles = (HufTile *) g.htiles.p;
+		a.htrec = (HufTRec *) g.htrec.p;
 		a.hrec = (uint32_t *) g.hrec.p;
 		a.hlist = (uint32_t *) g.hlist.p;
-		a.htbase = (uint32_t *) g.htbase.p;
 		a.hread = (uint32_t *) g.hread.p;
 		a.max_htiles = max_htiles_of(total_samples, nreads);
 		a.hlist_cap = (uint32_t) hlist_cap_of(a.max_htiles);

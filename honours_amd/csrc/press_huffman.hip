@@ -4,33 +4,31 @@
 // started at a wrong bit position falls back onto true code boundaries after a few codes.
 // The payload of every read is cut into SUBSEQUENCES of OWN bits (256 for the NA12878 table,
 // whose shortest code has 4 bits), one lane each; a TILE = 256 subsequences (8 KiB) = one
-// workgroup.  Nothing in the two heavy kernels waits for anything: no chain, no look-back,
-// no barrier besides the table load - the dependences between subsequences are settled by
-// small kernels in between, over 4-byte records:
+// 256-thread workgroup at a time.  Nothing in the two heavy kernels waits for another tile:
 //
-//   k_huf_sync   lane i runs through the RU = OWN/2 bits in front of its subsequence from
-//                their first bit (a guess that is right in ~97 % of the cases once it has
-//                crossed into its own subsequence), then through its own subsequence, with a
-//                LENGTH-ONLY table: one LDS look-up consumes every whole code that fits in 12
-//                bits (up to three 4-bit codes).  No symbol is produced.  Record of the
-//                subsequence: {f = where its first code starts (as assumed), e = where the first
-//                code of the next subsequence starts, c = codes that start in it}.
-//                The lane's bits live in a private LDS column (dword j of lane l at j*64 + l:
-//                any mix of per-lane positions is bank-conflict free, and nothing is shared,
-//                so no barrier).
-//   k_huf_links  link i holds iff f[i] == e[i-1].  A record behind a chain of holding links
-//   k_huf_fix    that starts at the read's first subsequence is true.  Broken links (3 %) are
-//                listed (leftmost of each run) and one lane per run re-decodes from the true
-//                start; a fix that moves the end breaks the next link, which the next round
-//                picks up: three rounds leave a handful (0.03^3).
-//   k_huf_chain  one wave per read walks its records: repairs what is left serially (this
-//                alone is enough for ANY table and stream - a code whose lengths share a factor
-//                never synchronises - the rounds before it are only faster), sums the counts
-//                per tile and settles how many values the read delivers.
-//   k_huf_emit   lane i decodes its subsequence once more from its true start, now with the
-//                two-symbol table, straight into the one-byte stream at its final position
-//                (in-tile scan of the counts + the tile's base): 4-byte stores at byte
-//                addresses, no staging.
+//   k_huf_sync   where do codes start?  Lengths only: one LDS look-up takes every whole code that fits
+//                in 12 bits.  Lane i runs through the RU = OWN/2 bits in front of its subsequence from
+//                their first bit: where that run crosses into its own subsequence is its guess of the
+//                first code's start (right in ~97 % of the cases); then through its own subsequence.
+//                Lanes whose guess is not where the left neighbour ended are decoded again from there -
+//                by wave 0, which takes the tile's few such lanes together - until every link of the
+//                tile holds.  Leaves a record per subsequence {start, codes} and per tile {start it
+//                assumed, where the next tile's first code starts, codes}.
+//                The lane's bits live in a private LDS column (dword j of lane l at j*64 + l: any mix
+//                of per-lane positions is bank-conflict free); a lane's run-up reads its neighbour's.
+//                The loops are wave-uniform with predicated bodies; while 12 bits are left in front of
+//                the limit nothing can step over it, so the body is one look-up fed from a register
+//                window over the column (the dword behind the window is fetched while the look-up is in
+//                flight); the last few codes take a careful loop.
+//   k_huf_tlinks tiles whose assumed start is not where the tile in front ended (3 %) are listed and
+//   k_huf_sync   done again from the true start (the same kernel over the list), twice.
+//   k_huf_chain  one workgroup per read: what is still broken is repaired serially, tile after tile
+//                (this alone is enough for ANY table and stream - a code whose lengths share a factor
+//                never synchronises - the rounds before it are only faster); then the codes in front
+//                of every tile and what the read delivers.
+//   k_huf_emit   lane i decodes its subsequence once more from its true start, now with the two-symbol
+//                table, into the wave's LDS staging buffer at its final order (scan of the counts);
+//                the buffer leaves with 16-byte stores.
 //
 // Result == huffman.c:1219 bit for bit, including its behaviour at the end of the input
 // (stops when the bytes run out or the symbol count is reached; a code cut off by the end
@@ -41,18 +39,11 @@
 namespace ph {
 
 constexpr uint32_t HEND = 0xFFFFFFFFu; // "no further code": end of input or an undecodable prefix
-constexpr uint32_t R_END = 31;         // the same in a record's 5-bit position fields
-constexpr uint32_t R_FIRST = 1u << 31; // record flag: first subsequence of its read (its start is exact)
+constexpr uint32_t R_END = 31;         // the same in a record's position fields
 constexpr int HT = HUF_HT;
 
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
-
-// record = f | e << 5 | c << 10 (| R_FIRST): f, e relative to the start of the own / the next
-// subsequence (0 .. longest code - 1, or R_END), c <= 64
-__device__ __forceinline__ uint32_t rec_pack(uint32_t f, uint32_t e, uint32_t c) { return f | (e << 5) | (c << 10); }
-__device__ __forceinline__ uint32_t rec_f(uint32_t r) { return r & 31u; }
-__device__ __forceinline__ uint32_t rec_e(uint32_t r) { return (r >> 5) & 31u; }
-__device__ __forceinline__ uint32_t rec_c(uint32_t r) { return (r >> 10) & 127u; }
+__device__ __forceinline__ bool any64(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
 
 // inclusive scan over the 64 lanes of a wave (DPP row shifts + row broadcasts)
 __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
@@ -66,20 +57,11 @@ __device__ __forceinline__ uint32_t wave_scan(uint32_t v)
 	return v;
 }
 
-// A code the 12-bit tables cannot resolve: longer than HUF_LUT_BITS bits (second-level table, or
-// the trie for prefixes beyond the first HUF_L2_IDS), or no code at all.  wnd = 32 stream bits.
-// -> length | symbol << 8 | LC_OK, or 0 if the bits are no code.  (Rare: kept out of line.)
-constexpr uint32_t LC_OK = 1u << 31;
-__device__ __noinline__ uint32_t long_code(const HuffDev *hd, uint32_t wnd)
+// A code beyond the second-level tables (prefixes past the first HUF_L2_IDS, tables that do not
+// fit): the trie in global memory.  wnd = 32 stream bits.  -> a one-code lut32 entry, or 0 if the
+// bits are no code.  (Very rare: kept out of line.)
+__device__ __noinline__ uint32_t trie_code(const HuffDev *hd, uint32_t wnd)
 {
-	const uint32_t e1 = hd->lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
-	if (e1 != 0xFFFFu && !(e1 & 0x8000u)) // (callers come here for long codes only; be complete)
-		return (e1 >> 8) | ((e1 & 0xFFu) << 8) | LC_OK;
-	if (e1 != 0xFFFFu) {
-		const uint32_t id = e1 & 0xFFu;
-		const uint32_t e2 = hd->lut2[hd->l2off[id] + ((wnd >> HUF_LUT_BITS) & ((1u << hd->l2bits[id]) - 1u))];
-		return e2 == 0xFFFFu ? 0u : ((e2 >> 8) | ((e2 & 0xFFu) << 8) | LC_OK);
-	}
 	int node = 0;
 	uint32_t l = 0;
 	while (node >= 0 && hd->leaf[node] < 0 && l < 32) {
@@ -88,21 +70,71 @@ __device__ __noinline__ uint32_t long_code(const HuffDev *hd, uint32_t wnd)
 	}
 	if (node < 0 || hd->leaf[node] < 0)
 		return 0;
-	return l | ((uint32_t) hd->leaf[node] << 8) | LC_OK;
+	return (uint32_t) hd->leaf[node] | (l << 8) | (l << 24);
 }
 
-// ---- the lane's bits: a private LDS column, dword j of lane l at col[j * 64] ----
+// columns: the subsequence and the reach of a code that starts in its last bit, one dword for the
+// window prefetch of the scan loops
+template <int RU>
+struct HufGeo {
+	static constexpr int OWN = 2 * RU;
+	static constexpr int NDW = OWN / 32 + 1; // dwords that are loaded
+	static constexpr int NCOL = NDW + 1;     // dwords a column has
+};
 
-// Count the codes that start in [start, lim) of the column (bit positions relative to the
-// column), stopping at the payload end nb; returns where the next code starts, or HEND.
-// One look-up takes every whole code that fits in 12 bits.  Two loops: while 12 bits are left in
-// front of the limit nothing can step over it, so the body is a look-up and two additions, fed
-// from a register window over the column (the dword after the window is fetched while the look-up
-// is in flight: one LDS round trip per step); the last few codes take the careful loop.
-// Wave-uniform loops with predicated bodies: lanes need different numbers of steps, and per-lane
-// branches cost more than the few masked operations.
-__device__ __forceinline__ uint32_t col_scan(const uint32_t *col, const uint16_t *mlut, const HuffDev *hd,
-					     uint32_t start, uint32_t lim, uint32_t nb, uint32_t &cnt)
+__device__ __forceinline__ uint32_t clamp_nb(int64_t v)
+{
+	return v <= 0 ? 0u : (v > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t) v);
+}
+
+// Stage NDW dwords of the tile from byte offset rb0 (a multiple of 4, possibly negative: the
+// run-up of a tile's first lane lies in the previous tile) into a column.  Bytes outside
+// the payload [lo, nby) read as zero.  Lanes whose dwords all lie inside issue their loads back
+// to back (16-byte loads at any byte address).
+template <int NDW>
+__device__ __forceinline__ void col_load(uint32_t *col, const uint8_t *src, int32_t rb0, int32_t lo, int32_t nby)
+{
+	if (rb0 >= lo && rb0 + 4 * NDW <= nby) {
+		const uint8_t *q = src + rb0;
+		uint4 t[NDW / 4 ? NDW / 4 : 1];
+		uint32_t x[NDW % 4 ? NDW % 4 : 1];
+#pragma unroll
+		for (int j = 0; j < NDW / 4; j++)
+			__builtin_memcpy(&t[j], q + 16 * j, 16);
+#pragma unroll
+		for (int j = 0; j < NDW % 4; j++)
+			__builtin_memcpy(&x[j], q + 4 * (NDW / 4 * 4 + j), 4);
+#pragma unroll
+		for (int j = 0; j < NDW / 4; j++) {
+			col[(4 * j + 0) * 64] = t[j].x;
+			col[(4 * j + 1) * 64] = t[j].y;
+			col[(4 * j + 2) * 64] = t[j].z;
+			col[(4 * j + 3) * 64] = t[j].w;
+		}
+#pragma unroll
+		for (int j = 0; j < NDW % 4; j++)
+			col[(NDW / 4 * 4 + j) * 64] = x[j];
+	} else {
+		for (int j = 0; j < NDW; j++) { // rolled: the ends of a payload only
+			const int32_t r = rb0 + 4 * j;
+			uint32_t x = 0;
+			if (r + 4 > lo && r < nby) {
+				for (int i = 0; i < 4; i++)
+					if (r + i >= lo && r + i < nby)
+						x |= (uint32_t) src[r + i] << (8 * i);
+			}
+			col[j * 64] = x;
+		}
+	}
+}
+
+// Count the codes that start in [start, lim) of a column (bit positions relative to the column),
+// stopping at the payload end nb; returns where the next code starts, or HEND.
+// mlut entry: total bits | codes << 4 | bits of the first code << 8 of every whole code that fits in
+// 12 bits; long codes (13 .. 24 bits: one code in 200 of the NA12878 table, one look-up in four has
+// such a lane) through the second-level table of lengths.
+__device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint16_t *mlut, const uint8_t *l2len,
+					     const HuffDev *hd, uint32_t start, uint32_t lim, uint32_t nb, uint32_t &cnt)
 {
 	bool bad = start == HEND;
 	uint32_t p = bad ? 0u : start;
@@ -110,44 +142,52 @@ __device__ __forceinline__ uint32_t col_scan(const uint32_t *col, const uint16_t
 	if (bad)
 		L = 0;
 	uint32_t c = 0;
+	// length of a long code; 0: the bits are no code
+	auto long_len = [&](uint32_t e, uint32_t wnd) -> uint32_t {
+		if (e == 0xFFFFu)
+			return (trie_code(hd, wnd) >> 24) & 31u; // beyond the second level: the trie in global memory
+		const uint32_t l = l2len[((e & 0x7FFu) << 1) + ((wnd >> HUF_LUT_BITS) & ((1u << ((e >> 11) & 15u)) - 1u))];
+		return l == 0xFFu ? 0u : l;
+	};
 	{
+		int32_t Lm = (int32_t) L - HUF_LUT_BITS; // every code of a look-up starts below L while p <= Lm
 		uint32_t j = p >> 5;
 		uint32_t w0 = col[j * 64], w1 = col[(j + 1) * 64];
 		const uint32_t *pf = col + (j + 2) * 64;
-		bool stuck = false; // a long code that needs the careful loop
 		for (;;) {
-			const bool act = p + HUF_LUT_BITS <= L && !stuck;
-			if (!__any(act))
+			const bool act = (int32_t) p <= Lm;
+			if (!any64(act))
 				break;
-			const uint32_t w2 = *pf; // (columns have room for this read behind the last code's reach)
+			const uint32_t w2 = *pf; // (the row behind the last column keeps this read inside the array)
 			const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p); // shift = p & 31
 			const uint32_t e = mlut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
 			uint32_t tot = e & 15u, n = (e >> 4) & 15u;
 			bool ok = act;
-			if (__any(act && e == 0xFFFFu)) { // rare: a long code, or none
-				if (act && e == 0xFFFFu) {
-					const uint32_t r = long_code(hd, wnd);
-					tot = r & 31u;
+			if (any64(act && (e & 0x8000u))) {
+				if (act && (e & 0x8000u)) {
+					tot = long_len(e, wnd);
 					n = 1;
-					if (!(r & LC_OK) || p + tot > L) {
-						ok = false;
-						stuck = true;
+					if (tot == 0 || p + tot > L) { // no code, or it ends behind the limit:
+						ok = false;            // the careful loop decides
+						Lm = -1;
 					}
 				}
 			}
-			p += ok ? tot : 0u;
-			c += ok ? n : 0u;
+			if (ok) {
+				p += tot;
+				c += n;
+			}
 			const uint32_t jn = p >> 5; // a step crosses at most one dword
 			const bool st = jn != j;
 			w0 = st ? w1 : w0;
 			w1 = st ? w2 : w1;
-			pf += st ? 64 : 0;
+			pf = col + (jn + 2) * 64;
 			j = jn;
 		}
 	}
 	for (;;) {
 		const bool act = p < L;
-		if (!__any(act))
+		if (!any64(act))
 			break;
 		const uint32_t pp = act ? p : 0u;
 		const uint32_t j = pp >> 5;
@@ -155,19 +195,19 @@ __device__ __forceinline__ uint32_t col_scan(const uint32_t *col, const uint16_t
 		const uint32_t e = mlut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
 		uint32_t tot = e & 15u, n = (e >> 4) & 15u, len1 = (e >> 8) & 15u;
 		bool fail = false;
-		if (__any(act && e == 0xFFFFu)) {
-			if (act && e == 0xFFFFu) {
-				const uint32_t r = long_code(hd, wnd);
-				fail = !(r & LC_OK);
-				tot = len1 = r & 31u;
+		if (any64(act && (e & 0x8000u))) {
+			if (act && (e & 0x8000u)) {
+				tot = len1 = long_len(e, wnd);
+				fail = tot == 0;
 				n = 1;
 			}
 		}
-		const bool fits = pp + tot <= L;             // every code of the group starts below L, ends inside the payload
-		const bool cut = !fits && pp + len1 > nb;    // a code cut off by the end of the input is not delivered
-		const bool go = act && !fail && !cut;
-		p += go ? (fits ? tot : len1) : 0u;
-		c += go ? (fits ? n : 1u) : 0u;
+		const bool fits = pp + tot <= L;          // every code of the group starts below L, ends inside the payload
+		const bool cut = !fits && pp + len1 > nb; // a code cut off by the end of the input is not delivered
+		if (act && !fail && !cut) {
+			p += fits ? tot : len1;
+			c += fits ? n : 1u;
+		}
 		if (act && (fail || cut)) {
 			bad = true;
 			L = 0;
@@ -177,293 +217,261 @@ __device__ __forceinline__ uint32_t col_scan(const uint32_t *col, const uint16_t
 	return bad ? HEND : (p >= nb && p < lim ? HEND : p);
 }
 
-// The same walk from global memory, one code per step, for the few subsequences that are decoded
-// again (k_huf_fix, k_huf_chain): bits [start, lim) of a tile whose payload has nb bits from src on.
-__device__ __noinline__ uint32_t slow_scan(const uint8_t *src, const HuffDev *hd, uint32_t start, uint32_t lim,
-					  uint64_t nb64, uint32_t &cnt)
-{
-	cnt = 0;
-	if (start == HEND)
-		return HEND;
-	const uint32_t nb = nb64 > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t) nb64;
-	const uint32_t L = lim < nb ? lim : nb;
-	const uint32_t nby = (nb + 7) >> 3;
-	uint32_t p = start, c = 0;
-	while (p < L) {
-		uint64_t w = 0;
-		const uint32_t b0 = p >> 3;
-		for (uint32_t i = 0; i < 5 && b0 + i < nby; i++)
-			w |= (uint64_t) src[b0 + i] << (8 * i);
-		const uint32_t wnd = (uint32_t) (w >> (p & 7u));
-		const uint32_t r = long_code(hd, wnd);
-		const uint32_t len = r & 31u;
-		if (!(r & LC_OK) || p + len > nb)
-			return cnt = c, HEND;
-		p += len;
-		c++;
-	}
-	cnt = c;
-	return p >= nb && p < lim ? HEND : p;
-}
+// ------------------------------------------------------------------ one tile
 
-// Stage NDW dwords of the tile from byte offset rb0 (a multiple of 4, possibly negative: the
-// run-up of a tile's first lane lies in the previous tile) into the lane's column.  Bytes outside
-// the payload [lo, nby) read as zero.  Lanes whose dwords all lie inside issue their loads back
-// to back (16-byte loads at any byte address).
-template <int NDW>
-__device__ __forceinline__ void col_load(uint32_t *col, const uint8_t *src, int32_t rb0, int32_t lo, int32_t nby)
-{
-	uint32_t v[NDW];
-	if (rb0 >= lo && rb0 + 4 * NDW <= nby) {
-		const uint8_t *q = src + rb0;
-#pragma unroll
-		for (int j = 0; j + 4 <= NDW; j += 4) {
-			uint4 t;
-			__builtin_memcpy(&t, q + 4 * j, 16);
-			v[j] = t.x;
-			v[j + 1] = t.y;
-			v[j + 2] = t.z;
-			v[j + 3] = t.w;
-		}
-#pragma unroll
-		for (int j = NDW & ~3; j < NDW; j++)
-			__builtin_memcpy(&v[j], q + 4 * j, 4);
-	} else {
-#pragma unroll
-		for (int j = 0; j < NDW; j++) {
-			const int32_t r = rb0 + 4 * j;
-			uint32_t x = 0;
-			if (r + 4 > lo && r < nby) {
-				for (int i = 0; i < 4; i++)
-					if (r + i >= lo && r + i < nby)
-						x |= (uint32_t) src[r + i] << (8 * i);
-			}
-			v[j] = x;
-		}
-	}
-#pragma unroll
-	for (int j = 0; j < NDW; j++)
-		col[j * 64] = v[j];
-}
-
-// ------------------------------------------------------------------ k_huf_sync
-
-// columns: the subsequence, the reach of a code that starts in its last bit, two dwords for the
-// window prefetch of col_scan
 template <int RU>
-struct HufGeo {
-	static constexpr int OWN = 2 * RU;
-	static constexpr int NDW = OWN / 32 + 1; // dwords that are loaded
-	static constexpr int NCOL = NDW + 2;     // dwords a column has
+struct TileLds { // what a workgroup keeps per tile besides the tables
+	static constexpr int NCOL = HufGeo<RU>::NCOL;
+	// column of lane l of wave w: img[w + 1] + l; img[0] + 63 = the last subsequence of the tile in front;
+	// one row behind the last column for len_scan's prefetch
+	uint32_t img[HT / 64 + 1][NCOL * 64];
+	uint32_t pad_row[64];
+	uint8_t s_f[HT], s_e[HT], s_c[HT], s_list[HT];
+	uint32_t s_nl[2];
+	uint32_t wtot[HT / 64];
 };
 
-__device__ __forceinline__ uint32_t clamp_nb(int64_t v)
-{
-	return v <= 0 ? 0u : (v > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t) v);
-}
+constexpr uint32_t NO_START = 0xFFu;
 
-template <int RU> // run-up bits; the subsequence itself has 2 * RU
-__global__ __launch_bounds__(HT) void k_huf_sync(DecodeArgs a)
+// Tile k (all 256 threads of the workgroup call this).  start: NO_START = the first lane runs
+// up through the tile in front like every other lane; else the position (0 .. 30 / R_END) where
+// the tile's first code starts.  Leaves the subsequences' records in a.hrec, the tile's in
+// a.htrec[k] and its `se` also as the return value (same in every thread).
+template <int RU>
+__device__ __forceinline__ uint32_t sync_tile(const DecodeArgs &a, uint32_t k, uint32_t start, TileLds<RU> &T,
+					      const uint16_t *lut, const uint8_t *lut2)
 {
-	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW, NCOL = HufGeo<RU>::NCOL;
-	__shared__ uint16_t mlut[1 << HUF_LUT_BITS];
-	// column of lane l of wave w: img[w + 1] + l; img[0] + 63 = the last subsequence of the tile in front
-	__shared__ uint32_t img[HT / 64 + 1][NCOL * 64];
-	__shared__ uint8_t s_e[HT], s_list[HT];
-	__shared__ uint32_t s_nl;
-
+	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW;
 	const uint32_t tid = threadIdx.x;
-	const uint32_t ntiles = min(uniform(a.ctl->nchunks), a.max_htiles);
-	if (blockIdx.x >= ntiles)
-		return;
+	const uint32_t lane = tid & 63;
+	const HufTile *dp = a.htiles + k;
+	const uint32_t nbits_t = uniform(dp->nbits);
+	const uint32_t t = uniform(dp->t_last) & 0x7FFFFFFFu;
+	const uint8_t *src = a.in + dp->src;
+	const int32_t nby = (int32_t) ((nbits_t + 7) >> 3); // (nbits_t < 2^32: below 2^29 bytes)
+	uint32_t *col = T.img[(tid >> 6) + 1] + lane;
+	const uint32_t *rcol = T.img[(tid + 63) >> 6] + ((tid + 63) & 63); // the left neighbour's column
+	const bool exact = t == 0 || start != NO_START; // the first lane's start is known
+
+	col_load<NDW>(col, src, (int32_t) tid * (OWN / 8), 0, nby);
+	if (tid == 0 && !exact) // the bits in front of the tile belong to the same payload
+		col_load<NDW>(T.img[0] + 63, src, -(OWN / 8), -(OWN / 8), nby);
+	if (tid == 0)
+		T.s_nl[0] = T.s_nl[1] = 0;
+	__syncthreads(); // columns (a lane's run-up reads its neighbour's) - and whatever the caller staged
+	// payload end in the coordinates of the own / the neighbour's column
+	const uint32_t nb = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN);
+	const uint32_t nbr = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN + OWN);
+
+	// ---- run-up through the second half of the subsequence in front, then the own one
+	const bool first_known = tid == 0 && exact;
+	uint32_t f, c0, c;
 	{
-		const uint4 *s4 = reinterpret_cast<const uint4 *>(a.huff->mlut);
-		uint4 *d4 = reinterpret_cast<uint4 *>(mlut);
-		for (uint32_t i = tid; i < (1u << HUF_LUT_BITS) / 8; i += HT)
-			d4[i] = s4[i];
+		const uint32_t g = len_scan(rcol, lut, lut2, a.huff, first_known ? HEND : (uint32_t) RU, OWN, nbr, c0);
+		f = g == HEND ? HEND : g - OWN;
+		if (g == HEND && nb > 0)
+			f = 0; // the guess ran into a bit pattern that is no code: any guess will do
+		if (first_known)
+			f = t == 0 ? 0u : (start == R_END ? HEND : start);
 	}
-	uint32_t *col = img[(tid >> 6) + 1] + (tid & 63);
-	const uint32_t *rcol = img[((tid + 63) >> 6)] + ((tid + 63) & 63); // the left neighbour's column
-	// persistent workgroups: the table is loaded once
-	for (uint32_t k = blockIdx.x; k < ntiles; k += gridDim.x) {
-		const HufTile *dp = a.htiles + k;
-		const uint32_t nbits_t = uniform(dp->nbits);
-		const uint32_t t = uniform(dp->t_last) & 0x7FFFFFFFu;
-		const uint8_t *src = a.in + dp->src;
-		const int32_t nby = (int32_t) ((nbits_t + 7) >> 3); // (nbits_t < 2^32: below 2^29 bytes)
-		col_load<NDW>(col, src, (int32_t) tid * (OWN / 8), 0, nby);
-		if (tid == 0 && t) // the bits in front of the tile belong to the same payload
-			col_load<NDW>(img[0] + 63, src, -(OWN / 8), -(OWN / 8), nby);
-		if (tid == 0)
-			s_nl = 0;
-		__syncthreads(); // columns (a lane's run-up reads its neighbour's), the table
-		// payload end in the coordinates of the own / the neighbour's column
-		const uint32_t nb = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN);
-		const uint32_t nbr = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN + OWN);
+	const uint32_t e = len_scan(col, lut, lut2, a.huff, f, OWN, nb, c);
+	T.s_f[tid] = (uint8_t) (f == HEND ? R_END : f);
+	T.s_e[tid] = (uint8_t) (e == HEND ? R_END : e - OWN);
+	T.s_c[tid] = (uint8_t) c;
 
-		// ---- run-up through the second half of the subsequence in front, then the own one
-		const bool exact = t == 0 && tid == 0; // a read's first subsequence starts at its bit 0
-		uint32_t f = 0, c0, c;
-		if (!__all(exact)) {
-			const uint32_t g = col_scan(rcol, mlut, a.huff, exact ? HEND : (uint32_t) RU, OWN, nbr, c0);
-			f = g == HEND ? HEND : g - OWN;
-			if (g == HEND && nb > 0)
-				f = 0; // the guess ran into a bit pattern that is no code: any guess will do
-			if (exact)
-				f = 0;
-		}
-		const uint32_t e = col_scan(col, mlut, a.huff, f, OWN, nb, c);
-		const uint32_t fr = f == HEND ? R_END : f, er = e == HEND ? R_END : e - OWN;
-
-		// ---- first repair round inside the tile: a lane whose assumed start is not where its left
-		// neighbour ended (3 %) is decoded again from there - by wave 0, which takes the tile's few
-		// such lanes together (their columns are still in LDS).  The first lane's link leaves the
-		// tile, and a repair that moves an end breaks the next link: the rounds below.
-		s_e[tid] = (uint8_t) er;
+	// ---- repair rounds: a lane whose assumed start is not where its left neighbour ended (3 %) is
+	// decoded again from there; thread i is final after at most i rounds, in practice after one or two
+	for (uint32_t par = 0;; par ^= 1u) {
 		__syncthreads();
-		const bool broken = tid > 0 && fr != s_e[tid - 1];
+		const bool broken = tid > 0 && T.s_f[tid] != T.s_e[tid - 1];
 		const unsigned long long bm = __ballot(broken);
 		if (bm) {
 			uint32_t base = 0;
-			if ((tid & 63) == 0)
-				base = atomicAdd(&s_nl, (uint32_t) __popcll(bm));
+			if (lane == 0)
+				base = atomicAdd(&T.s_nl[par], (uint32_t) __popcll(bm));
 			base = (uint32_t) __shfl((int) base, 0, 64);
 			if (broken)
-				s_list[base + (uint32_t) __popcll(bm & ((1ull << (tid & 63)) - 1ull))] = (uint8_t) tid;
+				T.s_list[base + (uint32_t) __popcll(bm & ((1ull << lane) - 1ull))] = (uint8_t) tid;
 		}
-		if (!broken)
-			a.hrec[(uint64_t) k * HT + tid] = rec_pack(fr, er, c) | (exact ? R_FIRST : 0u);
+		if (tid == 0)
+			T.s_nl[par ^ 1u] = 0;
 		__syncthreads();
-		const uint32_t nl = s_nl;
+		const uint32_t nl = T.s_nl[par];
+		if (nl == 0)
+			break;
 		if (tid < 64) {
 			for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
 				const uint32_t i = i0 + tid;
 				const bool mine = i < nl;
-				const uint32_t u = mine ? s_list[i] : 1u;
-				const uint32_t pe = s_e[u - 1];
+				const uint32_t u = mine ? T.s_list[i] : 1u;
+				const uint32_t pe = T.s_e[u - 1];
 				uint32_t c2;
-				const uint32_t e2 = col_scan(img[(u >> 6) + 1] + (u & 63), mlut, a.huff,
+				const uint32_t e2 = len_scan(T.img[(u >> 6) + 1] + (u & 63), lut, lut2, a.huff,
 							     (!mine || pe == R_END) ? HEND : pe, OWN,
 							     clamp_nb((int64_t) nbits_t - (int64_t) u * OWN), c2);
-				if (mine)
-					a.hrec[(uint64_t) k * HT + u] = rec_pack(pe, e2 == HEND ? R_END : e2 - OWN, c2);
+				if (mine) {
+					T.s_f[u] = (uint8_t) pe;
+					T.s_e[u] = (uint8_t) (e2 == HEND ? R_END : e2 - OWN);
+					T.s_c[u] = (uint8_t) c2;
+				}
 			}
 		}
-		__syncthreads(); // the columns and lists are free again
+	}
+
+	// ---- the records: per subsequence {start, codes}, per tile {assumed start, end, codes}
+	const uint32_t cnt = T.s_c[tid];
+	a.hrec[(uint64_t) k * HT + tid] = (uint32_t) T.s_f[tid] | (cnt << 8);
+	const uint32_t inc = wave_scan(cnt);
+	if (lane == 63)
+		T.wtot[tid >> 6] = inc;
+	__syncthreads();
+	uint32_t total = 0;
+#pragma unroll
+	for (int w2 = 0; w2 < HT / 64; w2++)
+		total += T.wtot[w2];
+	const uint32_t se = (uint32_t) T.s_f[0] | ((uint32_t) T.s_e[HT - 1] << 8);
+	if (tid == 0) {
+		HufTRec r;
+		r.se = se;
+		r.count = total;
+		r.base = 0;
+		r.pad = 0;
+		a.htrec[k] = r;
+	}
+	__syncthreads(); // the columns and lists are free again
+	return se;
+}
+
+__device__ __forceinline__ void load_len_tables(const HuffDev *hd, uint16_t *mlut, uint8_t *l2len)
+{
+	const uint4 *s4 = reinterpret_cast<const uint4 *>(hd->mlut);
+	uint4 *d4 = reinterpret_cast<uint4 *>(mlut);
+	for (uint32_t i = threadIdx.x; i < (1u << HUF_LUT_BITS) / 8; i += HT)
+		d4[i] = s4[i];
+	const uint4 *t4 = reinterpret_cast<const uint4 *>(hd->l2len);
+	uint4 *u4 = reinterpret_cast<uint4 *>(l2len);
+	for (uint32_t i = threadIdx.x; i < (uint32_t) HUF_L2_ENTRIES / 16; i += HT)
+		u4[i] = t4[i];
+}
+
+// All tiles (LIST = false), or the tiles of a repair round: a.hlist = {tile, true start} pairs, their
+// number in ctl->ticket2.  Persistent workgroups: the tables are loaded once.
+template <int RU, bool LIST>
+__global__ __launch_bounds__(HT, 6) void k_huf_sync(DecodeArgs a)
+{
+	__shared__ __attribute__((aligned(16))) uint16_t lut[1 << HUF_LUT_BITS];
+	__shared__ __attribute__((aligned(16))) uint8_t lut2[HUF_L2_ENTRIES];
+	__shared__ TileLds<RU> T;
+
+	const uint32_t n = LIST ? min(uniform(a.ctl->ticket2), a.hlist_cap) : min(uniform(a.ctl->nchunks), a.max_htiles);
+	if (blockIdx.x >= n)
+		return;
+	load_len_tables(a.huff, lut, lut2);
+	for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+		const uint32_t k = LIST ? uniform(a.hlist[2 * i]) : i;
+		const uint32_t st = LIST ? uniform(a.hlist[2 * i + 1]) : NO_START;
+		(void) sync_tile<RU>(a, k, st, T, lut, lut2);
 	}
 }
 
-// ------------------------------------------------------------------ links, fix rounds
-
-// leftmost broken link of every run -> a.hlist (count in ctl->ticket2)
-__global__ __launch_bounds__(256) void k_huf_links(DecodeArgs a)
+// tiles whose assumed start is not where the tile in front ended -> a.hlist
+__global__ __launch_bounds__(256) void k_huf_tlinks(DecodeArgs a)
 {
-	const uint64_t nsub = (uint64_t) min(uniform(a.ctl->nchunks), a.max_htiles) * HT;
+	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63;
-	for (uint64_t g0 = (uint64_t) blockIdx.x * 256; g0 < nsub; g0 += (uint64_t) gridDim.x * 256) {
-		const uint64_t g = g0 + threadIdx.x;
-		const uint32_t r0 = a.hrec[g];
-		const uint32_t r1 = g >= 1 ? a.hrec[g - 1] : R_FIRST;
-		const uint32_t r2 = g >= 2 ? a.hrec[g - 2] : R_FIRST;
-		const bool br0 = !(r0 & R_FIRST) && rec_f(r0) != rec_e(r1);
-		const bool br1 = !(r1 & R_FIRST) && rec_f(r1) != rec_e(r2);
-		const bool lead = br0 && !br1;
-		const unsigned long long m = __ballot(lead);
-		if (m) {
-			uint32_t base = 0;
-			if (lane == 0)
-				base = atomicAdd(&a.ctl->ticket2, (uint32_t) __popcll(m));
-			base = (uint32_t) __shfl((int) base, 0, 64);
-			const uint32_t idx = base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
-			if (lead && idx < a.hlist_cap)
-				a.hlist[idx] = (uint32_t) g; // (g < 2^32: max_htiles * HT is checked on the host)
+	bool br = false;
+	uint32_t pe = 0;
+	if (k < min(a.ctl->nchunks, a.max_htiles) && (a.htiles[k].t_last & 0x7FFFFFFFu)) {
+		pe = (a.htrec[k - 1].se >> 8) & 0xFFu;
+		br = (a.htrec[k].se & 0xFFu) != pe;
+	}
+	const unsigned long long m = __ballot(br);
+	if (m) {
+		uint32_t base = 0;
+		if (lane == 0)
+			base = atomicAdd(&a.ctl->ticket2, (uint32_t) __popcll(m));
+		base = (uint32_t) __shfl((int) base, 0, 64);
+		const uint32_t idx = base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+		if (br && idx < a.hlist_cap) {
+			a.hlist[2 * idx] = k;
+			a.hlist[2 * idx + 1] = pe;
 		}
 	}
 }
 
-// decode subsequence g again from column-relative start `f` (0 .. / R_END); -> the new record
+// One workgroup per read: repair what the rounds left (serially - always correct), then the codes in
+// front of every tile and what the read delivers (huffman.c:1243: at most `want` values).
 template <int RU>
-__device__ __forceinline__ uint32_t redo_sub(const DecodeArgs &a, uint64_t g, uint32_t f)
+__global__ __launch_bounds__(HT, 6) void k_huf_chain(DecodeArgs a)
 {
-	constexpr uint32_t OWN = 2 * RU;
-	const HufTile *dp = a.htiles + (g / HT);
-	const uint32_t tid = (uint32_t) (g % HT);
-	uint32_t c = 0;
-	const uint32_t e = slow_scan(a.in + dp->src, a.huff, f == R_END ? HEND : tid * OWN + f, (tid + 1) * OWN, dp->nbits, c);
-	return rec_pack(f, e == HEND ? R_END : e - (tid + 1) * OWN, c);
-}
+	__shared__ __attribute__((aligned(16))) uint16_t lut[1 << HUF_LUT_BITS];
+	__shared__ __attribute__((aligned(16))) uint8_t lut2[HUF_L2_ENTRIES];
+	__shared__ TileLds<RU> T;
+	__shared__ uint32_t s_first;
+	__shared__ uint32_t s_w[HT / 64];
 
-// one lane per run of broken links: walk it from its left end (see the file header)
-template <int RU>
-__global__ __launch_bounds__(256) void k_huf_fix(DecodeArgs a)
-{
-	const uint64_t nsub = (uint64_t) min(a.ctl->nchunks, a.max_htiles) * HT;
-	const uint32_t nl = min(a.ctl->ticket2, a.hlist_cap);
-	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nl; i += gridDim.x * 256) {
-		uint64_t g = a.hlist[i];
-		uint32_t prev_e = rec_e(a.hrec[g - 1]); // a lead's predecessor link holds: its record stands
-		for (;;) {
-			const uint32_t old = a.hrec[g];
-			uint32_t now = old;
-			if (rec_f(old) != prev_e) {
-				now = redo_sub<RU>(a, g, prev_e);
-				a.hrec[g] = now;
-			}
-			// on into g + 1 only if that link was broken when the round began (then nobody else owns it)
-			if (g + 1 >= nsub)
-				break;
-			const uint32_t nx = a.hrec[g + 1];
-			if ((nx & R_FIRST) || rec_f(nx) == rec_e(old))
-				break;
-			prev_e = rec_e(now);
-			g++;
-		}
-	}
-}
-
-// ------------------------------------------------------------------ k_huf_chain
-
-// One wave per read: what the rounds left (serially, always correct), the codes in front of every
-// tile, and what the read delivers (huffman.c:1243: at most `want` values).
-template <int RU>
-__global__ __launch_bounds__(64) void k_huf_chain(DecodeArgs a)
-{
 	const uint32_t r = blockIdx.x;
-	const uint32_t lane = threadIdx.x;
+	const uint32_t tid = threadIdx.x;
 	const uint32_t k0 = uniform(a.hread[2 * r]), nt = uniform(a.hread[2 * r + 1]);
 	if (!nt)
 		return;
-	const uint64_t g0 = (uint64_t) k0 * HT;
-	const uint32_t nsub = nt * HT;
-	uint64_t cum = 0;
-	uint32_t carry_e = 0; // end of the subsequence in front of the block
-	for (uint32_t b = 0; b < nsub; b += 64) {
-		uint32_t rec = a.hrec[g0 + b + lane];
-		for (;;) { // until every link of the block holds
-			uint32_t pe = (uint32_t) __shfl_up((int) rec_e(rec), 1, 64);
-			if (lane == 0)
-				pe = carry_e;
-			const bool br = !(rec & R_FIRST) && rec_f(rec) != pe;
-			const unsigned long long m = __ballot(br);
-			if (!m)
+	bool loaded = false;
+	for (uint32_t t0 = 1; t0 < nt;) {
+		// the first broken link at or behind t0
+		if (tid == 0)
+			s_first = 0xFFFFFFFFu;
+		__syncthreads();
+		for (uint32_t u = t0 + tid; u < nt; u += HT)
+			if ((a.htrec[k0 + u].se & 0xFFu) != ((a.htrec[k0 + u - 1].se >> 8) & 0xFFu)) {
+				atomicMin(&s_first, u);
 				break;
-			const uint32_t L = (uint32_t) __builtin_ctzll(m);
-			// everything left of lane L is true, so is its predecessor's end: decode it again (all lanes
-			// compute the same thing - this path is rare)
-			const uint32_t st = uniform((uint32_t) __shfl((int) pe, (int) L, 64));
-			const uint32_t now = redo_sub<RU>(a, g0 + b + L, st);
-			if (lane == L) {
-				rec = now;
-				a.hrec[g0 + b + lane] = now;
 			}
+		__syncthreads();
+		uint32_t u = s_first;
+		__syncthreads();
+		if (u == 0xFFFFFFFFu)
+			break;
+		if (!loaded) {
+			load_len_tables(a.huff, lut, lut2); // (sync_tile's first barrier covers it)
+			loaded = true;
 		}
-		carry_e = uniform((uint32_t) __shfl((int) rec_e(rec), 63, 64));
-		if ((b % HT) == 0 && lane == 0)
-			a.htbase[k0 + b / HT] = (uint32_t) (cum > 0xFFFFFFFFull ? 0xFFFFFFFFull : cum);
-		const uint32_t inc = wave_scan(rec_c(rec));
-		cum += uniform((uint32_t) __shfl((int) inc, 63, 64));
+		// decode from the true start, and on while that moves the end
+		uint32_t pe = (a.htrec[k0 + u - 1].se >> 8) & 0xFFu;
+		for (;;) {
+			const uint32_t se = sync_tile<RU>(a, k0 + u, pe, T, lut, lut2);
+			pe = (se >> 8) & 0xFFu;
+			u++;
+			if (u >= nt || (a.htrec[k0 + u].se & 0xFFu) == pe)
+				break;
+		}
+		t0 = u + 1;
 	}
-	if (lane == 0) {
+	// exclusive prefix of the tiles' counts
+	uint64_t cum = 0;
+	for (uint32_t b = 0; b < nt; b += HT) {
+		const uint32_t u = b + tid;
+		// (tiles decoded again above: read past this CU's L1, which may hold the records as they were)
+		const uint32_t c = u < nt ? __hip_atomic_load(&a.htrec[k0 + u].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+		const uint32_t inc = wave_scan(c);
+		if ((tid & 63) == 63)
+			s_w[tid >> 6] = inc;
+		__syncthreads();
+		uint32_t before = 0, total = 0;
+#pragma unroll
+		for (int w2 = 0; w2 < HT / 64; w2++) {
+			const uint32_t x = s_w[w2];
+			if (w2 < (int) (tid >> 6))
+				before += x;
+			total += x;
+		}
+		if (u < nt) {
+			const uint64_t bs = cum + before + inc - c;
+			a.htrec[k0 + u].base = bs > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) bs;
+		}
+		cum += total;
+		__syncthreads();
+	}
+	if (tid == 0) {
 		const uint32_t want = a.htiles[k0].want;
 		a.meta[r].nlow = cum < want ? (uint32_t) cum : want; // what huffman_decode_memory delivered
 	}
@@ -482,135 +490,160 @@ __device__ __forceinline__ void wave_lds_sync()
 
 constexpr uint32_t EMIT_STG = 3328; // staging bytes per wave: 52 per lane (NA12878: 47.4 on average, 64 at most)
 
-template <int RU>
-__global__ __launch_bounds__(HT) void k_huf_emit(DecodeArgs a)
+// The symbols of the codes that start in [p, L) of the column, at most nmine of them, to wp[0 ..]
+// (LDS staging or the one-byte stream itself).
+// lut entry: sym1 | adv << 8 | sym2 << 16 | len1 << 24 | HUF_TWO; long codes through lut2.
+template <typename WP>
+__device__ __forceinline__ void emit_codes(const uint32_t *col, const uint32_t *lut, const uint16_t *lut2,
+					   const HuffDev *hd, uint32_t p, uint32_t L, uint32_t nmine, WP wp)
 {
-	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW, NCOL = NDW + 1;
-	__shared__ uint32_t lut[1 << HUF_LUT_BITS];
-	__shared__ uint32_t img[HT / 64][NCOL * 64];
-	__shared__ __attribute__((aligned(16))) uint8_t stg_all[HT / 64][EMIT_STG];
-	__shared__ uint32_t wtot[2][HT / 64];
+	// a long code (13 .. 24 bits) as a one-code entry; 0: the bits are no code (cannot come up in
+	// front of L: k_huf_sync stopped counting there)
+	auto long_entry = [&](uint32_t e, uint32_t wnd) -> uint32_t {
+		if (e == 0xFFFFFFFFu)
+			return trie_code(hd, wnd);
+		const uint32_t e2 = lut2[(e & 0xFFFu) + ((wnd >> HUF_LUT_BITS) & ((1u << ((e >> 12) & 15u)) - 1u))];
+		return e2 == 0xFFFFu ? 0u : ((e2 & 0xFFu) | (e2 & 0x1F00u) | ((e2 & 0x1F00u) << 16));
+	};
+	uint32_t q = 0; // symbols written
+	{
+		// both codes of a look-up start below L while p <= Lm, and the quota has room for two while q <= qm
+		int32_t Lm = (int32_t) L - HUF_LUT_BITS;
+		const int32_t qm = (int32_t) nmine - 2;
+		uint32_t j = p >> 5;
+		uint32_t w0 = col[j * 64], w1 = col[(j + 1) * 64];
+		const uint32_t *pf = col + (j + 2) * 64;
+		for (;;) {
+			const bool act = (int32_t) p <= Lm && (int32_t) q <= qm;
+			if (!any64(act))
+				break;
+			const uint32_t w2 = *pf; // (the row behind the last column keeps this read inside the array)
+			const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p);
+			uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
+			bool ok = act;
+			if (any64(act && e >= HUF_LONG)) {
+				if (act && e >= HUF_LONG) {
+					e = long_entry(e, wnd);
+					if (e == 0 || p + ((e >> 8) & 0x1Fu) > L) {
+						ok = false;
+						Lm = -1;
+					}
+				}
+			}
+			if (ok) {
+				wp[q] = (uint8_t) e;
+				if (e & HUF_TWO)
+					wp[q + 1] = (uint8_t) (e >> 16);
+				q += 1u + ((e >> 29) & 1u);
+				p += (e >> 8) & 0x1Fu;
+			}
+			const uint32_t jn = p >> 5;
+			const bool st = jn != j;
+			w0 = st ? w1 : w0;
+			w1 = st ? w2 : w1;
+			pf = col + (jn + 2) * 64;
+			j = jn;
+		}
+	}
+	for (;;) { // the careful loop: the last codes of the subsequence / of the quota
+		const bool act = p < L && q < nmine;
+		if (!any64(act))
+			break;
+		const uint32_t pp = act ? p : 0u;
+		const uint32_t j = pp >> 5;
+		const uint32_t wnd = __builtin_amdgcn_alignbit(col[(j + 1) * 64], col[j * 64], pp);
+		uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
+		if (any64(act && e >= HUF_LONG)) {
+			if (act && e >= HUF_LONG)
+				e = long_entry(e, wnd);
+		}
+		const uint32_t len1 = (e >> 24) & 0x1Fu;
+		// the second code counts only if it starts inside and the quota has room
+		const bool two = (e & HUF_TWO) && pp + len1 < L && q + 2 <= nmine;
+		if (act) {
+			wp[q] = (uint8_t) e;
+			if (two)
+				wp[q + 1] = (uint8_t) (e >> 16);
+			p += two ? ((e >> 8) & 0x1Fu) : len1;
+			q += two ? 2u : 1u;
+		}
+	}
+}
 
-	const uint32_t tid = threadIdx.x;
+// two tiles side by side share the tables
+constexpr int WGE = 2 * HT;
+
+template <int RU>
+__global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
+{
+	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW, NCOL = HufGeo<RU>::NCOL;
+	__shared__ uint32_t lut[1 << HUF_LUT_BITS];
+	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
+	__shared__ uint32_t img[WGE / 64][NCOL * 64];
+	__shared__ uint32_t pad_row[64];
+	__shared__ __attribute__((aligned(16))) uint8_t stg_all[WGE / 64][EMIT_STG];
+	__shared__ uint32_t wtot[2][WGE / 64];
+
+	const uint32_t grp = threadIdx.x >> 8;
+	const uint32_t tid = threadIdx.x & 255u;
 	const uint32_t lane = tid & 63;
+	const uint32_t wv = threadIdx.x >> 6; // wave of the workgroup
 	const uint32_t ntiles = min(uniform(a.ctl->nchunks), a.max_htiles);
-	if (blockIdx.x >= ntiles)
+	if (2 * blockIdx.x >= ntiles)
 		return;
+	if (threadIdx.x == 0)
+		pad_row[0] = 0; // (keeps the row behind the columns alive)
 	{
 		const uint4 *s4 = reinterpret_cast<const uint4 *>(a.huff->lut32);
 		uint4 *d4 = reinterpret_cast<uint4 *>(lut);
-		for (uint32_t i = tid; i < (1u << HUF_LUT_BITS) / 4; i += HT)
+		for (uint32_t i = threadIdx.x; i < (1u << HUF_LUT_BITS) / 4; i += WGE)
 			d4[i] = s4[i];
+		const uint4 *t4 = reinterpret_cast<const uint4 *>(a.huff->lut2);
+		uint4 *u4 = reinterpret_cast<uint4 *>(lut2);
+		for (uint32_t i = threadIdx.x; i < (uint32_t) HUF_L2_ENTRIES / 8; i += WGE)
+			u4[i] = t4[i];
 	}
-	uint32_t *col = img[tid >> 6] + lane;
-	uint8_t *stg = stg_all[tid >> 6];
+	uint32_t *col = img[wv] + lane;
+	uint8_t *stg = stg_all[wv];
 	uint32_t par = 0;
-	for (uint32_t k = blockIdx.x; k < ntiles; k += gridDim.x, par ^= 1u) {
-		const HufTile *dp = a.htiles + k;
-		const uint32_t nbits_t = uniform(dp->nbits);
+	// persistent workgroups: the tables are loaded once
+	for (uint32_t k0 = 2 * blockIdx.x; k0 < ntiles; k0 += 2 * gridDim.x, par ^= 1u) {
+		const uint32_t k = k0 + grp;
+		const bool has = k < ntiles; // (an odd tile count leaves the last group idle: it only keeps the barrier)
+		const HufTile *dp = a.htiles + (has ? k : k0);
+		const uint32_t nbits_t = has ? uniform(dp->nbits) : 0u;
 		const uint32_t want = uniform(dp->want);
 		const uint8_t *src = a.in + dp->src;
 		uint8_t *low = a.low + dp->low;
 		col_load<NDW>(col, src, (int32_t) tid * (OWN / 8), 0, (int32_t) ((nbits_t + 7) >> 3));
 		const uint32_t nb = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN);
-		const uint32_t rec = a.hrec[(uint64_t) k * HT + tid];
-		const uint32_t cnt = rec_c(rec);
+		const uint32_t rec = has ? a.hrec[(uint64_t) k * HT + tid] : R_END;
+		const uint32_t cnt = rec >> 8;
 		const uint32_t inc = wave_scan(cnt);
 		if (lane == 63)
-			wtot[par][tid >> 6] = inc;
-		__syncthreads(); // the wave totals (and, the first time, the table); columns and staging are private
-		uint64_t obase = uniform(a.htbase[k]); // codes of the read in front of this wave
+			wtot[par][wv] = inc;
+		__syncthreads(); // the wave totals (and, the first time, the tables); columns and staging are private
+		uint64_t obase = has ? uniform(a.htrec[k].base) : 0u; // codes of the read in front of this wave
 #pragma unroll
 		for (int w2 = 0; w2 < HT / 64; w2++)
 			if (w2 < (int) (tid >> 6))
-				obase += uniform(wtot[par][w2]);
+				obase += uniform(wtot[par][grp * (HT / 64) + w2]);
 		const uint32_t wsum = uniform((uint32_t) __shfl((int) inc, 63, 64));
 		// the wave delivers values [obase, obase + wsum) of the read, cut at `want`
 		const uint32_t quota = obase >= want ? 0u : (wsum < want - (uint32_t) obase ? wsum : want - (uint32_t) obase);
 		const uint32_t ex = inc - cnt; // codes of the wave in front of this lane
 		const uint32_t nmine = ex >= quota ? 0u : (cnt < quota - ex ? cnt : quota - ex);
 		uint8_t *dst = low + obase;
-		// symbols go to the wave's staging buffer at their final order and leave it with 16-byte stores;
-		// a wave that holds more codes than the buffer takes (cannot happen with 5.4-bit codes on
-		// average) stores them byte by byte instead
-		const bool staged = wsum <= EMIT_STG;
-		uint8_t *wp = staged ? stg + ex : dst + ex;
-
-		// decode again, now with the symbols: sym1 | sym2 << 8 | len1 << 16 | (len1 + len2) << 21 | codes << 26
-		const uint32_t f = rec_f(rec);
-		uint32_t p = f == R_END ? 0u : f;
+		const uint32_t f = rec & 0xFFu;
+		const uint32_t p0 = f == R_END ? 0u : f;
 		uint32_t L = (uint32_t) OWN < nb ? (uint32_t) OWN : nb;
 		if (f == R_END || nmine == 0)
 			L = 0;
-		uint32_t q = 0; // symbols written
-		if (staged) {
-			uint32_t j = p >> 5;
-			uint32_t w0 = col[j * 64], w1 = col[(j + 1) * 64];
-			const uint32_t *pf = col + (j + 2) * 64;
-			bool stuck = false;
-			for (;;) { // both codes of a look-up start below L and the quota has room for two
-				const bool act = p + HUF_LUT_BITS <= L && q + 2 <= nmine && !stuck;
-				if (!__any(act))
-					break;
-				const uint32_t pfj = j + 2 < (uint32_t) NCOL ? 0u : 64u; // (stay inside the column)
-				const uint32_t w2 = *(pf - pfj);
-				const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p);
-				uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
-				bool ok = act;
-				if (__any(act && e >= HUF_LONG)) { // rare: a code longer than 12 bits
-					if (act && e >= HUF_LONG) {
-						const uint32_t r = long_code(a.huff, wnd);
-						const uint32_t len = r & 31u;
-						e = ((r >> 8) & 0xFFu) | (len << 16) | (len << 21) | (1u << 26);
-						if (!(r & LC_OK) || p + len > L) {
-							ok = false;
-							stuck = true;
-						}
-					}
-				}
-				const bool two = (e >> 27) != 0;
-				if (ok) {
-					wp[q] = (uint8_t) e;
-					if (two)
-						wp[q + 1] = (uint8_t) (e >> 8);
-				}
-				p += ok ? ((e >> 21) & 0x1Fu) : 0u;
-				q += ok ? (two ? 2u : 1u) : 0u;
-				const uint32_t jn = p >> 5;
-				const bool st = jn != j;
-				w0 = st ? w1 : w0;
-				w1 = st ? w2 : w1;
-				pf += st ? 64 : 0;
-				j = jn;
-			}
-		}
-		for (;;) { // the careful loop: the last codes of the subsequence / of the quota
-			const bool act = p < L && q < nmine;
-			if (!__any(act))
-				break;
-			const uint32_t pp = act ? p : 0u;
-			const uint32_t j = pp >> 5;
-			const uint32_t wnd = __builtin_amdgcn_alignbit(col[(j + 1) * 64], col[j * 64], pp);
-			uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
-			if (__any(act && e >= HUF_LONG)) { // (a pattern that is no code cannot come up: k_huf_sync
-				if (act && e >= HUF_LONG) {    // stopped counting in front of it)
-					const uint32_t r = long_code(a.huff, wnd);
-					const uint32_t len = r & 31u;
-					e = ((r >> 8) & 0xFFu) | (len << 16) | (len << 21) | (1u << 26);
-				}
-			}
-			const uint32_t len1 = (e >> 16) & 0x1Fu;
-			// the second code counts only if it starts inside and the quota has room
-			const bool two = (e >> 27) && pp + len1 < L && q + 2 <= nmine;
-			if (act) {
-				wp[q] = (uint8_t) e;
-				if (two)
-					wp[q + 1] = (uint8_t) (e >> 8);
-			}
-			p += act ? (two ? ((e >> 21) & 0x1Fu) : len1) : 0u;
-			q += act ? (two ? 2u : 1u) : 0u;
-		}
-		if (staged) {
+		// symbols go to the wave's staging buffer in their final order and leave it with 16-byte stores;
+		// a wave that holds more codes than the buffer takes (cannot happen with 5.4-bit codes on
+		// average) stores them byte by byte instead
+		if (wsum <= EMIT_STG) {
+			emit_codes(col, lut, lut2, a.huff, p0, L, nmine, stg + ex);
 			wave_lds_sync();
 			for (uint32_t o = lane * 16; o < quota; o += 64 * 16) {
 				const uint4 v = *reinterpret_cast<const uint4 *>(stg + o);
@@ -623,6 +656,8 @@ __global__ __launch_bounds__(HT) void k_huf_emit(DecodeArgs a)
 				}
 			}
 			wave_lds_sync(); // staging is free again
+		} else {
+			emit_codes(col, lut, lut2, a.huff, p0, L, nmine, dst + ex);
 		}
 	}
 }
@@ -689,17 +724,18 @@ __global__ __launch_bounds__(256) void k_huff_tiles(DecodeArgs a)
 template <int RU>
 static void run_huff_decode(const DecodeArgs &a, hipStream_t s)
 {
-	// persistent workgroups (the tables are loaded once per workgroup): what is resident, 7 / 4 per CU
+	// persistent workgroups: what is resident (6 per CU; emit: 2 of twice the size)
 	const uint32_t nt = a.max_htiles ? a.max_htiles : 1;
-	const uint32_t gs = nt < 7u * 256u ? nt : 7u * 256u, ge = nt < 4u * 256u ? nt : 4u * 256u;
-	hipLaunchKernelGGL((k_huf_sync<RU>), dim3(gs), dim3(HT), 0, s, a);
-	for (int round = 1; round < HUF_FIX_ROUNDS; round++) { // (round 0 ran inside k_huf_sync)
+	const uint32_t grid = nt < 6u * 256u ? nt : 6u * 256u;
+	const uint32_t ge = (nt + 1) / 2 < 2u * 256u ? (nt + 1) / 2 : 2u * 256u;
+	hipLaunchKernelGGL((k_huf_sync<RU, false>), dim3(grid), dim3(HT), 0, s, a);
+	for (int round = 0; round < HUF_FIX_ROUNDS; round++) {
 		(void) hipMemsetAsync(&a.ctl->ticket2, 0, 4, s);
-		hipLaunchKernelGGL(k_huf_links, dim3(2048), dim3(256), 0, s, a);
-		hipLaunchKernelGGL((k_huf_fix<RU>), dim3(1024), dim3(256), 0, s, a);
+		hipLaunchKernelGGL(k_huf_tlinks, dim3((nt + 255) / 256), dim3(256), 0, s, a);
+		hipLaunchKernelGGL((k_huf_sync<RU, true>), dim3(grid), dim3(HT), 0, s, a);
 	}
-	hipLaunchKernelGGL((k_huf_chain<RU>), dim3(a.nreads), dim3(64), 0, s, a);
-	hipLaunchKernelGGL((k_huf_emit<RU>), dim3(ge), dim3(HT), 0, s, a);
+	hipLaunchKernelGGL((k_huf_chain<RU>), dim3(a.nreads), dim3(HT), 0, s, a);
+	hipLaunchKernelGGL((k_huf_emit<RU>), dim3(ge), dim3(WGE), 0, s, a);
 }
 
 // Huffman stage of the exception-split decoders: payload of every read -> a.low

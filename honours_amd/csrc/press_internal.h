@@ -43,20 +43,32 @@ struct HuffDev {
 	uint16_t lut2[HUF_L2_ENTRIES];
 	uint16_t l2off[256];
 	uint8_t l2bits[256];
-	// two-symbol first level for the parallel decoder: sym1 | sym2 << 8 | len1 << 16 |
-	// (len1 + len2) << 21 | ncodes << 26, ncodes = 2 when two whole codes fit in HUF_LUT_BITS
-	// bits, else 1 (then the len1 + len2 field repeats len1); HUF_LONG | id for a long code's
-	// prefix; 0xFFFFFFFF: walk the trie
+	// two-symbol first level for the parallel decoder:
+	//   sym1 | adv << 8 | sym2 << 16 | len1 << 24 | HUF_TWO,  adv = len1 + len2 with HUF_TWO (two whole
+	//   codes fit in HUF_LUT_BITS bits), else adv = len1 and sym2 = 0
+	// (the two symbols sit in the low bytes of the two register halves: ds_write_b8 / _d16_hi store
+	// them without a shift); a long code's prefix: HUF_LONG | l2bits << 12 | l2off of its
+	// second-level table; 0xFFFFFFFF: walk the trie
 	alignas(16) uint32_t lut32[1 << HUF_LUT_BITS];
 	// length-only first level for k_huf_sync: every whole code that fits in HUF_LUT_BITS bits at once:
-	// total bits | codes << 4 | bits of the first code << 8; 0xFFFF: the first code is longer (or none)
+	// total bits | codes << 4 | bits of the first code << 8; a long code's prefix:
+	// 0x8000 | l2bits << 11 | l2off / 2 (its length is l2len[l2off + the next l2bits stream bits],
+	// 0xFF: no such code); 0xFFFF: walk the trie
 	alignas(16) uint16_t mlut[1 << HUF_LUT_BITS];
+	alignas(16) uint8_t l2len[HUF_L2_ENTRIES];
 };
 constexpr uint32_t HUF_LONG = 1u << 30;
+constexpr uint32_t HUF_TWO = 1u << 29;
 
 // parallel Huffman decode (press_huffman.hip): tiles of HUF_HT subsequences, one workgroup each
 constexpr int HUF_HT = 256;        // threads per workgroup = subsequences per tile
-constexpr int HUF_FIX_ROUNDS = 3;  // parallel repair rounds before the serial pass of k_huf_chain
+constexpr int HUF_FIX_ROUNDS = 2;  // parallel tile repair rounds before the serial pass of k_huf_chain
+struct HufTRec {             // what k_huf_sync leaves per tile (16 bytes)
+	uint32_t se;         // start it assumed | where the next tile's first code starts << 8 (0 .. 30, 31 = none)
+	uint32_t count;      // codes that start in the tile
+	uint32_t base;       // codes of the read in front of the tile (k_huf_chain)
+	uint32_t pad;
+};
 
 // ---- chunked (v2) svb kernels: a read is cut into chunks of CHUNK samples, one workgroup
 // per chunk; chunks of a read are chained by a decoupled look-back over 8-byte granules.
@@ -131,7 +143,7 @@ struct DecodeArgs {
 	ReadMeta *meta;
 	uint32_t *ex_pos;
 	uint32_t *ex_val;
-	uint8_t *low;             // [total samples] Huffman-decoded one-byte stream of read r at low[off[r]..]
+	uint8_t *low;             // [total samples] Huffman- / range-decoded one-byte stream of read r at low[off[r]..]
 	const HuffDev *huff;
 	uint32_t nreads;
 	// chunked kernels
@@ -142,9 +154,9 @@ struct DecodeArgs {
 	uint32_t max_chunks;
 	// Huffman tiles (press_huffman.hip)
 	HufTile *htiles;          // [max_htiles]
-	uint32_t *hrec;           // [max_htiles * HUF_HT] one record per subsequence
-	uint32_t *hlist;          // [hlist_cap] broken links of a repair round
-	uint32_t *htbase;         // [max_htiles] codes of the read in front of the tile
+	HufTRec *htrec;           // [max_htiles]
+	uint32_t *hrec;           // [max_htiles * HUF_HT] one record per subsequence: start | codes << 8
+	uint32_t *hlist;          // [2 * hlist_cap] tiles of a repair round: {tile, true start}
 	uint32_t *hread;          // [2 * nreads] first tile, number of tiles of read r
 	uint32_t max_htiles;
 	uint32_t hlist_cap;
