@@ -66,7 +66,7 @@ KERNELS = {
     "zstd_svb_zd": ("k_zs_encode", "k_zs_hdecode"),
     "zstd_svb12_zd": ("k_zs_encode", "k_zs_hdecode"),
     "zstd_hasgam_vbsse21_zdq": ("k_zs_encode", "k_zs_hdecode"),
-    "shuffman_vbe21_zd": ("k_huff_encode_chunked", "k_huff_decode_tiles"),
+    "shuffman_vbe21_zd": ("k_huff_encode_chunked", "k_huf_sync + repair rounds + k_huf_chain + k_huf_emit"),
 }
 # what bounds the dominant kernel, from the counter passes kept in profiles/ (DESIGN.md section 4):
 # "hbm" = streams at the memory system's rate; "valu" = instruction issue (HBM time of its bytes is a fraction)
@@ -79,8 +79,8 @@ def kernel_own_bytes(m, which, raw, comp, nsamp):
     """Bytes the timed kernel itself has to move once (its share of the call's 2n + c):
     the kernels of a multi-kernel pipeline hand intermediates to each other through HBM."""
     if m.startswith("shuffman"):
-        # encode: samples in, payload out; decode (k_huff_decode_tiles): payload in, the one-byte
-        # values out (k_low_decode_chunked<true> then reads them and writes the samples)
+        # encode: samples in, payload out; decode (k_huf_sync .. k_huf_emit, timed together): payload in,
+        # the one-byte values out (k_low_decode_chunked<true> then reads them and writes the samples)
         return raw + comp if which == 0 else comp + nsamp
     if m.startswith("zstd"):
         # k_zs_encode: inner stream (1.25 B/sample) in, frame out; k_zs_hdecode: frame in, literals out

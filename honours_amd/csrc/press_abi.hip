@@ -92,10 +92,11 @@ struct Ctx {
 	bool use_user = false;
 	// scratch shared by both modes
 	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, htrec, hrec, hlist, hread, cbits;
-	DevBuf ztmp, zoff, zoff4, zlen, zhist, ztab, zfirst, zblk, zsbits, zbpos, zbflag, zkcnt, zkbase, zrd, znb, zn, zdcopy, zdhuf, zdunit, zdtree, zdctl; // zstd frames
+	DevBuf ztmp, zoff, zoff4, zlen, zhist, ztab, zfirst, zblk, zsbits, zbpos, zbflag, zkcnt, zkbase, zrd, znb, zn, zdcopy, zdhuf, zdunit, zdtree, zdctl, zdseq, zdxblk; // zstd frames
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn, dense, dense_off;
 	uint64_t zs_total = 0; // total_samples of the batch in flight (sizes of the zstd scratch)
+	uint32_t zs_nhost = 0; // frames the last zstd depress batch left to libzstd
 	// static Huffman table currently on the device
 	bool have_table = false;
 	uint32_t tlen[256];
@@ -421,6 +422,14 @@ void zs_bufs(ZsBufs &z, uint64_t total_samples, uint32_t nreads, int method = PR
 	z.cap_copy = z.max_blocks + (uint32_t) (total_samples / 256) + 16 * nreads + 64;
 	z.cap_units = z.max_blocks / 8 + 2 * nreads + 64;
 	z.cap_trees = 4 * nreads + 64;
+	// frames with sequences (libzstd's own): their literals in the second half of ztmp
+	z.dseq = (ZsSeq *) g.zdseq.p;
+	z.dxblk = (ZsXBlk *) g.zdxblk.p;
+	z.lit_base = zs_tmp_bytes(method, total_samples, nreads);
+	// (level 1 on signal data: a handful per block; higher levels: one per ~20 content bytes)
+	const uint64_t cs = total_samples / 4 + 64ull * nreads + 1024;
+	z.cap_seq = cs > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t) cs;
+	z.cap_xblk = z.max_blocks / 4 + 4 * nreads + 64;
 }
 
 int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool decode)
@@ -436,8 +445,9 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 		ZsBufs z;
 		zs_bufs(z, total_samples, nreads, method);
 		const size_t nr = (size_t) nreads + 1;
-		if (g.ztmp.reserve(zs_tmp_bytes(method, total_samples, nreads)) || g.zoff.reserve(nr * 8) || g.zoff4.reserve(nr * 8) ||
+		if (g.ztmp.reserve(2 * zs_tmp_bytes(method, total_samples, nreads)) || g.zoff.reserve(nr * 8) || g.zoff4.reserve(nr * 8) ||
 		    g.zlen.reserve(nr * 8) || g.zrd.reserve(nr * sizeof(ZsRead)) || g.zn.reserve(nr * 4) ||
+		    g.zdseq.reserve((size_t) z.cap_seq * sizeof(ZsSeq)) || g.zdxblk.reserve((size_t) z.cap_xblk * sizeof(ZsXBlk)) ||
 		    g.zdcopy.reserve((size_t) z.cap_copy * sizeof(ZsCopy)) || g.zdhuf.reserve((size_t) z.cap_units * 8 * sizeof(ZsHuf)) ||
 		    g.zdunit.reserve((size_t) z.cap_units * sizeof(ZsUnit)) || g.zdtree.reserve((size_t) z.cap_trees * sizeof(ZsTree)) ||
 		    g.zdctl.reserve(64))
@@ -612,6 +622,12 @@ extern "C" void press_hip_shutdown(void)
 	g.use_user = false;
 	g.have_table = false;
 	g.ready = false;
+}
+
+extern "C" uint32_t press_hip_zstd_host_frames(void)
+{
+	API_LOCK;
+	return g.zs_nhost;
 }
 
 extern "C" uint32_t press_hip_scratch_buffers(uint64_t *bytes)
@@ -956,6 +972,7 @@ static int zs_host_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t s)
 	ZsDCtl c;
 	HIPCHK(hipMemcpyAsync(&c, z.dctl, sizeof c, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
+	g.zs_nhost = c.nhost;
 	if (!c.nhost || !zstd_open())
 		return 0; // without libzstd those reads fail
 	const uint32_t nr = a.nreads;

@@ -172,7 +172,8 @@ struct ZsRead {               // per read
 	uint32_t plen;        // bytes in front of the keys: the count / the ex-zd header and exception section
 	uint32_t pad[2];
 };
-// ZsRead on the decode side: nd = content size of the frame, mode 0 ok / 2 malformed / 3 left to libzstd
+// ZsRead on the decode side: nd = content size of the frame, mode 0 ok / 2 malformed / 3 left to libzstd,
+// pad[0] = its first block with sequences + 1 (0: none)
 struct ZsCopy {               // content bytes [dst, dst + n) of ztmp: a copy of n bytes at src of the arena, or its byte n times
 	uint64_t src, dst;
 	uint32_t n, fill;
@@ -190,8 +191,19 @@ struct ZsTree {
 	uint8_t w[256];       // weights (RFC 8878 4.2.1.1)
 	uint32_t tl, pad[3];
 };
+struct ZsSeq {               // one sequence: ll literals, then ml bytes from off bytes back
+	uint32_t ll, ml, off;
+};
+struct ZsXBlk {              // a block with sequences, in the order of its frame
+	uint64_t lit;        // ztmp offset of its literals
+	uint64_t dst;        // ztmp offset of its content
+	uint32_t seq0, nseq; // its sequences in dseq
+	uint32_t tail;       // literals behind the last match
+	uint32_t next;       // the frame's next such block + 1, 0: none
+};
 struct ZsDCtl {
 	uint32_t ncopy, nunits, ntrees, nhost;
+	uint32_t nseq, nxblk, pad[2];
 };
 struct ZsBufs {
 	uint8_t *ztmp;        // the svb-zd streams between the two stages: [u32 n][keys][data] of read r at zoff[r]
@@ -217,6 +229,10 @@ struct ZsBufs {
 	ZsTree *dtree;        // [cap_trees]
 	ZsDCtl *dctl;
 	uint32_t *zn;         // [nreads] sample count found in the stream
+	ZsSeq *dseq;          // [cap_seq] sequences of the frames' blocks
+	ZsXBlk *dxblk;        // [cap_xblk]
+	uint64_t lit_base;    // ztmp offset of the literals space (read r's at lit_base + zoff[r])
+	uint32_t cap_seq, cap_xblk;
 	uint32_t cap_copy, cap_units, cap_trees;
 	uint32_t kdiv;        // samples per key byte of the inner stream: 4 (svb-zd), 8 (svb16-zd), 0: ex-zd (no keys)
 };

@@ -842,9 +842,9 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 //
 // k_zs_layout -> k_zs_walk (one lane per read: zs::walk_frame checks the frame and lists its
 // pieces) -> k_zs_copy (raw / RLE pieces) + k_zs_hdecode (one lane per Huffman stream) ->
-// [the caller lets libzstd do the frames the walk left to it] -> k_zs_finish -> svb-zd decode.
-// Frames of this library never need libzstd; neither do libzstd's own as long as a frame has
-// no sequences.
+// k_zs_exec (one wave per frame: the sequences of libzstd's own frames) -> [the caller lets libzstd do
+// the frames the walk left to it: dictionaries, 12-bit Huffman tables, several frames in one stream]
+// -> k_zs_finish -> svb-zd decode.  Neither this library's frames nor ZSTD_compress's need libzstd.
 
 namespace {
 
@@ -860,6 +860,8 @@ struct DevSink {
 	bool overflow;
 
 	uint32_t cbase, cleft;      // copy slots taken eight at a time (one atomic), unused ones are cleared
+	uint64_t lit_abs = 0;       // ztmp offset of the frame's literals space
+	uint32_t first_xblk = 0, cur_xblk = 0, seq0 = 0; // blocks with sequences: the frame's chain, the one being filled
 
 	__device__ uint32_t take(uint32_t *ctr, uint32_t n = 1)
 	{
@@ -895,7 +897,7 @@ struct DevSink {
 					z.dcopy[cbase + j].n = 0;
 		cleft = 0;
 	}
-	__device__ void push_copy(uint64_t src, uint64_t dst, uint32_t n, uint32_t fill)
+	__device__ void push_copy(uint64_t src, uint64_t dst, uint32_t n, uint32_t fill, bool lit)
 	{
 		if (!n)
 			return;
@@ -908,7 +910,7 @@ struct DevSink {
 		if (i < z.cap_copy) {
 			ZsCopy c;
 			c.src = in_base + src;
-			c.dst = out_base + dst;
+			c.dst = (lit ? lit_abs : out_base) + dst;
 			c.n = n;
 			c.fill = fill;
 			if ((threadIdx.x & 63) == 0)
@@ -917,8 +919,50 @@ struct DevSink {
 			overflow = true;
 		}
 	}
-	__device__ void copy(uint64_t src, uint64_t dst, uint32_t n) { push_copy(src, dst, n, 0); }
-	__device__ void fill(uint64_t src, uint64_t dst, uint32_t n) { push_copy(src, dst, n, 1); }
+	__device__ void copy(uint64_t src, uint64_t dst, uint32_t n, bool lit) { push_copy(src, dst, n, 0, lit); }
+	__device__ void fill(uint64_t src, uint64_t dst, uint32_t n, bool lit) { push_copy(src, dst, n, 1, lit); }
+	// a block with sequences: a record of its own, chained to the frame's earlier ones, and room for
+	// its sequences (k_zs_exec carries them out)
+	__device__ int64_t seq_block(uint32_t nseq, uint64_t lit, uint32_t R, uint64_t dst)
+	{
+		(void) R;
+		const uint32_t b = take(&z.dctl->nxblk);
+		const uint32_t q = take(&z.dctl->nseq, nseq);
+		if (b >= z.cap_xblk || (uint64_t) q + nseq > z.cap_seq)
+			return zs::W_HOST;
+		if ((threadIdx.x & 63) == 0) {
+			ZsXBlk x;
+			x.lit = lit_abs + lit;
+			x.dst = out_base + dst;
+			x.seq0 = q;
+			x.nseq = nseq;
+			x.tail = 0;
+			x.next = 0;
+			z.dxblk[b] = x;
+			if (cur_xblk)
+				z.dxblk[cur_xblk - 1].next = b + 1;
+		}
+		if (!first_xblk)
+			first_xblk = b + 1;
+		cur_xblk = b + 1;
+		seq0 = q;
+		return 0;
+	}
+	__device__ void seq(uint32_t i, uint32_t ll, uint32_t ml, uint32_t off)
+	{
+		if ((threadIdx.x & 63) == 0) {
+			ZsSeq q;
+			q.ll = ll;
+			q.ml = ml;
+			q.off = off;
+			z.dseq[seq0 + i] = q;
+		}
+	}
+	__device__ void seq_end(uint32_t tail)
+	{
+		if ((threadIdx.x & 63) == 0)
+			z.dxblk[cur_xblk - 1].tail = tail;
+	}
 	__device__ void close_unit()
 	{
 		if (unit != 0xFFFFFFFFu && (threadIdx.x & 63) == 0) {
@@ -946,7 +990,7 @@ struct DevSink {
 		cur_tree = i;
 		return 0;
 	}
-	__device__ int64_t huf(uint64_t src, uint32_t cs, uint64_t dst, uint32_t R, bool four)
+	__device__ int64_t huf(uint64_t src, uint32_t cs, uint64_t dst, uint32_t R, bool four, bool lit)
 	{
 		if (unit == 0xFFFFFFFFu || ucount == ZU) {
 			close_unit();
@@ -957,7 +1001,7 @@ struct DevSink {
 		}
 		ZsHuf h;
 		h.src = in_base + src;
-		h.dst = out_base + dst;
+		h.dst = (lit ? lit_abs : out_base) + dst;
 		h.cs = cs;
 		h.R = R;
 		h.four = four;
@@ -980,6 +1024,7 @@ __global__ __launch_bounds__(256) void k_zs_walk(DecodeArgs a, ZsBufs z)
 	const uint32_t cap_n = a.nsamp[r];
 	const uint64_t cap = zs_content_max(cap_n, z.kdiv); // what zs_slot() leaves room for
 	DevSink sink{ z, a.in_off[r], z.zoff[r], r, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, false, 0, 0 };
+	sink.lit_abs = z.lit_base + z.zoff[r];
 	int64_t L = zs::walk_frame(a.in + a.in_off[r], a.in_len[r], cap, sink, work);
 	sink.close_unit();
 	sink.close_copies();
@@ -989,7 +1034,8 @@ __global__ __launch_bounds__(256) void k_zs_walk(DecodeArgs a, ZsBufs z)
 		return;
 	ZsRead rd;
 	rd.nk = rd.knz = rd.dbase = rd.plen = 0;
-	rd.pad[0] = rd.pad[1] = 0;
+	rd.pad[0] = L >= 0 ? sink.first_xblk : 0;
+	rd.pad[1] = 0;
 	rd.nd = L >= 0 ? (uint32_t) L : 0;
 	rd.mode = L >= 0 ? 0 : L == zs::W_HOST ? 3 : 2;
 	z.rd[r] = rd;
@@ -1267,6 +1313,91 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	}
 }
 
+// Blocks with sequences (libzstd's own frames: the reference's streams, press.c:1462-1469): one wave
+// per frame carries them out in order - ll literals from the literals space, then ml bytes from off
+// bytes back in the content, which may be bytes the same wave has just written (a match may even
+// overlap itself): the wave waits for its stores before the next copy and reads the match source past
+// the CU's L1.  Runs behind k_zs_copy / k_zs_hdecode (literals and the other blocks are in place).
+__device__ __forceinline__ void wave_copy_plain(uint8_t *d, const uint8_t *s, uint32_t n)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	for (uint32_t k = lane * 16; k < n; k += 64 * 16) {
+		if (k + 16 <= n) {
+			uint4 v;
+			__builtin_memcpy(&v, s + k, 16);
+			__builtin_memcpy(d + k, &v, 16);
+		} else {
+			for (uint32_t e = k; e < n; e++)
+				d[e] = s[e];
+		}
+	}
+}
+__device__ __forceinline__ uint8_t ld_l2(const uint8_t *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wave_match(uint8_t *d, uint32_t off, uint32_t n)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	const uint8_t *s = d - off;
+	if (off >= n) { // no overlap
+		for (uint32_t k = lane * 8; k < n; k += 64 * 8) {
+			if (k + 8 <= n) {
+				uint64_t v = 0;
+				for (int b = 0; b < 8; b++)
+					v |= (uint64_t) ld_l2(s + k + b) << (8 * b);
+				__builtin_memcpy(d + k, &v, 8);
+			} else {
+				for (uint32_t e = k; e < n; e++)
+					d[e] = ld_l2(s + e);
+			}
+		}
+		return;
+	}
+	// the match overlaps itself: the off bytes in front of it, repeated
+	if (off == 1) {
+		const uint32_t v4 = ld_l2(s) * 0x01010101u;
+		for (uint32_t k = lane * 16; k < n; k += 64 * 16) {
+			if (k + 16 <= n) {
+				const uint4 v = make_uint4(v4, v4, v4, v4);
+				__builtin_memcpy(d + k, &v, 16);
+			} else {
+				for (uint32_t e = k; e < n; e++)
+					d[e] = (uint8_t) v4;
+			}
+		}
+		return;
+	}
+	for (uint32_t k = lane; k < n; k += 64)
+		d[k] = ld_l2(s + k % off);
+}
+
+__global__ __launch_bounds__(256) void k_zs_exec(DecodeArgs a, ZsBufs z)
+{
+	const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (r >= a.nreads)
+		return;
+	uint32_t b = z.rd[r].mode == 0 ? z.rd[r].pad[0] : 0;
+	while (b) {
+		const ZsXBlk x = z.dxblk[b - 1];
+		const uint8_t *lit = z.ztmp + x.lit;
+		uint8_t *out = z.ztmp + x.dst;
+		for (uint32_t i = 0; i < x.nseq; i++) {
+			const ZsSeq q = z.dseq[x.seq0 + i];
+			wave_copy_plain(out, lit, q.ll);
+			lit += q.ll;
+			out += q.ll;
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the bytes written so far have reached L2
+			wave_match(out, q.off, q.ml);
+			out += q.ml;
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		wave_copy_plain(out, lit, x.tail);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		b = x.next;
+	}
+}
+
 __global__ __launch_bounds__(256) void k_zs_finish(DecodeArgs a, ZsBufs z)
 {
 	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
@@ -1304,6 +1435,7 @@ void launch_zstd_decode_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t
 	ktime_begin(1, s);
 	hipLaunchKernelGGL(k_zs_hdecode, dim3((z.cap_units + 1) / 2), dim3(64), 0, s, a, z);
 	ktime_end(1, s);
+	hipLaunchKernelGGL(k_zs_exec, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
 }
 
 void launch_zstd_decode_streams(const DecodeArgs &a, const ZsBufs &z, hipStream_t s)

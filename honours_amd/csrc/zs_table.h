@@ -515,6 +515,13 @@ ZS_FN uint32_t back_read(BackBits &b, uint32_t n) // the n <= 16 bits below pos,
 
 // scratch of the reading side (LDS on the device, where every lane of a wave runs the same walk)
 constexpr uint32_t WIN = 32; // frame bytes fetched at a time by walk_frame
+// FSE decoding table of one of the three sequence symbol types (RFC 8878 3.1.1.3.2.1): at most 9 bits
+struct SeqTab {
+	uint8_t sym[512], nb[512];
+	uint16_t nw[512];
+	uint32_t log;   // table log; 0 with one entry: an RLE table
+	uint32_t valid;
+};
 struct ReadWork {
 	uint8_t win[WIN];
 	uint8_t w[256];
@@ -522,6 +529,11 @@ struct ReadWork {
 	uint8_t dsym[64], dnb[64];
 	uint16_t dnew[64], next[16];
 	int norm[16];
+	// sequences
+	SeqTab st[3];      // literal lengths, offsets, match lengths
+	int norm2[64];
+	uint16_t next2[64];
+	uint8_t sdesc[512]; // the sequence section's table descriptions (all three tables: below 400 bytes)
 };
 
 // FSE-compressed weights (FSE_decompress with table log <= 6) -> w[0..count); 0: malformed
@@ -696,15 +708,231 @@ ZS_FN uint32_t read_tree(const uint8_t *p, uint32_t avail, uint8_t *w, uint32_t 
 	return tl > (uint32_t) MAXLEN ? 0xFFFFFFFFu : used;
 }
 
+// ---- sequences (RFC 8878 3.1.1.3.2): three FSE-coded symbol streams interleaved in one backward bit stream
+
+ZS_FN uint32_t back_read32(BackBits &b, uint32_t n) // n <= 32
+{
+	if (n <= 16)
+		return back_read(b, n);
+	const uint32_t hi = back_read(b, n - 16);
+	return (hi << 16) | back_read(b, 16);
+}
+
+// normalised counts of an FSE table description (FSE_readNCount) at f -> norm[0..*nsym); returns the bytes
+// used, 0: malformed
+ZS_FN uint32_t fse_read_ncount(const uint8_t *src, uint32_t len, int *norm, uint32_t maxsym, uint32_t maxlog,
+			       uint32_t *tlog, uint32_t *nsym)
+{
+	FwdBits f{ src, len, 0 };
+	const uint32_t tl = fwd_peek(f, 4) + 5;
+	f.pos += 4;
+	if (tl > maxlog)
+		return 0;
+	const int ts = 1 << tl;
+	int remaining = ts + 1, threshold = ts, nbits = (int) tl + 1;
+	uint32_t charnum = 0;
+	bool prev0 = false;
+	while (remaining > 1 && charnum <= maxsym) {
+		if (prev0) {
+			uint32_t n0 = charnum;
+			while (fwd_peek(f, 16) == 0xFFFFu) {
+				n0 += 24;
+				f.pos += 16;
+				if (f.pos > 8 * len)
+					return 0;
+			}
+			while (fwd_peek(f, 2) == 3) {
+				n0 += 3;
+				f.pos += 2;
+				if (f.pos > 8 * len)
+					return 0;
+			}
+			n0 += fwd_peek(f, 2);
+			f.pos += 2;
+			if (n0 > maxsym)
+				return 0;
+			while (charnum < n0)
+				norm[charnum++] = 0;
+		}
+		const int max = (2 * threshold - 1) - remaining;
+		const int pk = (int) fwd_peek(f, (uint32_t) nbits);
+		int count;
+		if ((pk & (threshold - 1)) < max) {
+			count = pk & (threshold - 1);
+			f.pos += (uint32_t) nbits - 1;
+		} else {
+			count = pk & (2 * threshold - 1);
+			if (count >= threshold)
+				count -= max;
+			f.pos += (uint32_t) nbits;
+		}
+		count--;
+		remaining -= count < 0 ? -count : count;
+		norm[charnum++] = count;
+		prev0 = count == 0;
+		while (remaining < threshold) {
+			nbits--;
+			threshold >>= 1;
+		}
+	}
+	if (remaining != 1 || f.pos > 8 * len)
+		return 0;
+	*tlog = tl;
+	*nsym = charnum;
+	return (f.pos + 7) / 8;
+}
+
+// decoding table from normalised counts (FSE_buildDTable); false: the counts do not fill the table
+ZS_FN bool fse_build_seqtab(const int *norm, uint32_t nsym, uint32_t tl, SeqTab &t, uint16_t *next)
+{
+	const int ts = 1 << tl;
+	int high = ts - 1;
+	for (uint32_t s = 0; s < nsym; s++) {
+		if (norm[s] == -1) {
+			t.sym[high--] = (uint8_t) s;
+			next[s] = 1;
+		} else {
+			next[s] = (uint16_t) norm[s];
+		}
+	}
+	const int step = (ts >> 1) + (ts >> 3) + 3, mask = ts - 1;
+	int pos = 0;
+	for (uint32_t s = 0; s < nsym; s++)
+		for (int i = 0; i < norm[s]; i++) {
+			t.sym[pos] = (uint8_t) s;
+			pos = (pos + step) & mask;
+			while (pos > high)
+				pos = (pos + step) & mask;
+		}
+	if (pos != 0)
+		return false;
+	for (int u = 0; u < ts; u++) {
+		const uint32_t sy = t.sym[u];
+		const uint32_t nx = next[sy]++;
+		const uint32_t nb = tl - highbit(nx);
+		t.nb[u] = (uint8_t) nb;
+		t.nw[u] = (uint16_t) ((nx << nb) - (uint32_t) ts);
+	}
+	t.log = tl;
+	t.valid = 1;
+	return true;
+}
+
+// the predefined distributions (RFC 8878 3.1.1.3.2.2.1/2/3)
+ZS_FN int seq_default_norm(int which, uint32_t s)
+{
+	if (which == 0) { // literal lengths, 36 symbols, log 6
+		return s == 0 ? 4 : s == 1 ? 3 : s <= 12 ? 2 : s <= 15 ? 1 : s <= 24 ? 2 : s == 25 ? 3 : s == 26 ? 2 : s <= 31 ? 1 : -1;
+	}
+	if (which == 1) // offsets, 29 symbols, log 5
+		return s <= 5 ? 1 : s <= 8 ? 2 : s <= 23 ? 1 : -1;
+	// match lengths, 53 symbols, log 6
+	return s == 0 ? 1 : s == 1 ? 4 : s == 2 ? 3 : s <= 8 ? 2 : s <= 45 ? 1 : -1;
+}
+
+// base value and extra bits of a literal-length / match-length code
+ZS_FN uint32_t ll_base(uint32_t c, uint32_t *bits)
+{
+	if (c < 16) {
+		*bits = 0;
+		return c;
+	}
+	if (c < 20) {
+		*bits = 1;
+		return 16 + 2 * (c - 16);
+	}
+	if (c < 22) {
+		*bits = 2;
+		return 24 + 4 * (c - 20);
+	}
+	if (c < 24) {
+		*bits = 3;
+		return 32 + 8 * (c - 22);
+	}
+	if (c == 24) {
+		*bits = 4;
+		return 48;
+	}
+	*bits = c - 19; // 25 -> 6 bits, base 64; 26 -> 7, 128; ... 35 -> 16, 65536
+	return 1u << (c - 19);
+}
+ZS_FN uint32_t ml_base(uint32_t c, uint32_t *bits)
+{
+	if (c < 32) {
+		*bits = 0;
+		return c + 3;
+	}
+	if (c < 36) {
+		*bits = 1;
+		return 35 + 2 * (c - 32);
+	}
+	if (c < 38) {
+		*bits = 2;
+		return 43 + 4 * (c - 36);
+	}
+	if (c < 40) {
+		*bits = 3;
+		return 51 + 8 * (c - 38);
+	}
+	if (c < 42) {
+		*bits = 4;
+		return 67 + 16 * (c - 40);
+	}
+	if (c == 42) {
+		*bits = 5;
+		return 99;
+	}
+	*bits = c - 36; // 43 -> 7 bits, base 131; 44 -> 8, 259; ... 52 -> 16, 65539
+	return (1u << (c - 36)) + 3;
+}
+
+// One table of a sequence section: mode 0 predefined, 1 RLE, 2 FSE description, 3 the table of the block
+// before.  p / avail: the section bytes from here on; returns the bytes used, 0xFFFFFFFF: malformed.
+ZS_FN uint32_t seq_table(int which, uint32_t mode, const uint8_t *p, uint32_t avail, ReadWork &k)
+{
+	const uint32_t maxsym = which == 0 ? 35 : which == 1 ? 31 : 52;
+	const uint32_t maxlog = which == 1 ? 8 : 9;
+	SeqTab &t = k.st[which];
+	if (mode == 0) {
+		const uint32_t ns = which == 0 ? 36 : which == 1 ? 29 : 53;
+		for (uint32_t s = 0; s < ns; s++)
+			k.norm2[s] = seq_default_norm(which, s);
+		return fse_build_seqtab(k.norm2, ns, which == 1 ? 5 : 6, t, k.next2) ? 0 : 0xFFFFFFFFu;
+	}
+	if (mode == 1) {
+		if (avail < 1 || p[0] > maxsym)
+			return 0xFFFFFFFFu;
+		t.sym[0] = p[0];
+		t.nb[0] = 0;
+		t.nw[0] = 0;
+		t.log = 0;
+		t.valid = 1;
+		return 1;
+	}
+	if (mode == 2) {
+		uint32_t tl, ns;
+		const uint32_t used = fse_read_ncount(p, avail, k.norm2, maxsym, maxlog, &tl, &ns);
+		if (!used || !fse_build_seqtab(k.norm2, ns, tl, t, k.next2))
+			return 0xFFFFFFFFu;
+		return used;
+	}
+	return t.valid ? 0 : 0xFFFFFFFFu; // repeat
+}
+
 // ---- frames.  walk_frame() checks a frame and hands its pieces to a sink:
 //   sink.fetch(dst, src, n)           n frame bytes for the walk itself (dst: the window / the description buffer)
-//   sink.copy(src, dst, n)            n bytes of the frame at offset src are the content at dst
-//   sink.fill(src, dst, n)            the byte at src, n times
+//   sink.copy(src, dst, n, lit)       n bytes of the frame at offset src are the content at dst (lit: the bytes at
+//                                     dst of the frame's LITERALS space instead - a block with sequences)
+//   sink.fill(src, dst, n, lit)       the byte at src, n times
 //   sink.tree(w, tl) -> 0 / W_*       the Huffman table from here on: weights of the 256 bytes, table log
-//   sink.huf(src, csize, dst, R, four) -> 0 / W_*   Huffman-coded literals: csize bytes at src (jump table first
-//                                     when `four`) are R bytes at dst
+//   sink.huf(src, csize, dst, R, four, lit) -> 0 / W_*   Huffman-coded literals: csize bytes at src (jump table
+//                                     first when `four`) are R bytes at dst
+//   sink.seq_block(nseq, lit, R, dst) -> 0 / W_*   a block with nseq sequences: its R literals sit at `lit` of the
+//                                     literals space, its content starts at dst
+//   sink.seq(i, ll, ml, off)          sequence i: ll literals, then ml bytes from `off` bytes back in the content
+//   sink.seq_end(tail)                the block's last `tail` literals follow its last match
 // Returns the content size, or W_BAD (malformed) / W_HOST (valid zstd this reader leaves to
-// libzstd: sequences, dictionaries, 12-bit tables, several frames).
+// libzstd: dictionaries, 12-bit tables, several frames, more sequences than the sink takes).
 constexpr int64_t W_BAD = -1, W_HOST = -2;
 
 // Frame bytes come through a window of WIN bytes that the sink fills (sink.fetch(dst, src, n):
@@ -720,9 +948,10 @@ template <class Sink> struct FrameSrc {
 	ZS_FN uint32_t operator[](uint64_t i) // i < len
 	{
 		if (!valid || i < base || i >= base + WIN) {
-			base = i;
+			// (a backward reader - the sequences' bit stream - gets the bytes in front of i as well)
+			base = valid && i < base ? (i >= WIN - 1 ? i - (WIN - 1) : 0) : i;
 			valid = true;
-			sink.fetch(k.win, f + i, len - i < WIN ? (uint32_t) (len - i) : WIN);
+			sink.fetch(k.win, f + base, len - base < WIN ? (uint32_t) (len - base) : WIN);
 		}
 		return k.win[i - base];
 	}
@@ -752,7 +981,8 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, 
 	if (fcs_bytes == 2)
 		fcs += 256;
 	at += fcs_bytes;
-	uint64_t dst = 0;
+	uint64_t dst = 0, lit_pos = 0; // content so far; literals of the blocks with sequences so far
+	uint32_t rep[3] = { 1, 4, 8 };  // repeat offsets (RFC 8878 3.1.1.5)
 	bool have_tree = false;
 	for (;;) {
 		if (at + 3 > len)
@@ -766,13 +996,13 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, 
 		if (type == 0) {
 			if (at + bs > len || dst + bs > cap)
 				return W_BAD;
-			sink.copy(at, dst, bs);
+			sink.copy(at, dst, bs, false);
 			at += bs;
 			dst += bs;
 		} else if (type == 1) {
 			if (at + 1 > len || dst + bs > cap)
 				return W_BAD;
-			sink.fill(at, dst, bs);
+			sink.fill(at, dst, bs, false);
 			at += 1;
 			dst += bs;
 		} else {
@@ -798,16 +1028,37 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, 
 				R = (uint32_t) (v >> 4) & ((1u << kb) - 1);
 				cs = (uint32_t) (v >> (4 + kb)) & ((1u << kb) - 1);
 			}
-			if (R > 131072 || dst + R > cap || at + lh + cs + 1 > end)
+			if (R > 131072 || at + lh + cs + 1 > end)
 				return W_BAD;
-			// what follows the literals must be "no sequences" and the end of the block
-			if (f[at + lh + cs] != 0 || at + lh + cs + 1 != end)
-				return W_HOST;
+			// ---- the sequences section header behind the literals
+			const uint64_t sq = at + lh + cs;
+			uint32_t nseq = f[sq], shl = 1;
+			if (nseq >= 128) {
+				if (sq + 2 > end)
+					return W_BAD;
+				if (nseq < 255) {
+					nseq = ((nseq - 128) << 8) + f[sq + 1];
+					shl = 2;
+				} else {
+					if (sq + 3 > end)
+						return W_BAD;
+					nseq = f[sq + 1] + (f[sq + 2] << 8) + 0x7F00;
+					shl = 3;
+				}
+			}
+			const bool seqs = nseq != 0;
+			if (!seqs && sq + 1 != end)
+				return W_BAD;
+			if (!seqs && dst + R > cap)
+				return W_BAD;
+			// literals: straight into the content when no sequences follow, else into the frame's
+			// literals space (lit = true) from which the sequences copy them
 			uint64_t src = at + lh;
+			const uint64_t ldst = seqs ? lit_pos : dst;
 			if (lt == 0) {
-				sink.copy(src, dst, R);
+				sink.copy(src, ldst, R, seqs);
 			} else if (lt == 1) {
-				sink.fill(src, dst, R);
+				sink.fill(src, ldst, R, seqs);
 			} else {
 				if (lt == 2) {
 					uint8_t *w = k.w;
@@ -832,13 +1083,113 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, 
 				if (four ? (cs < 10 || R < 4) : cs < 1)
 					return W_BAD;
 				if (R) {
-					const int64_t e = sink.huf(src, cs, dst, R, four);
+					const int64_t e = sink.huf(src, cs, ldst, R, four, seqs);
 					if (e)
 						return e;
 				}
 			}
+			uint32_t produced = R;
+			if (seqs) {
+				// ---- tables (literal lengths, offsets, match lengths), then the backward bit stream
+				uint64_t q = sq + shl;
+				if (q + 1 > end)
+					return W_BAD;
+				const uint32_t modes = f[q++];
+				if (modes & 3)
+					return W_BAD;
+				const uint32_t dn = end - q < sizeof k.sdesc ? (uint32_t) (end - q) : (uint32_t) sizeof k.sdesc;
+				sink.fetch(k.sdesc, fp + q, dn);
+				uint32_t used_all = 0;
+				for (int which = 0; which < 3; which++) {
+					const uint32_t mode = (modes >> (6 - 2 * which)) & 3;
+					const uint32_t used = seq_table(which, mode, k.sdesc + used_all, dn - used_all, k);
+					if (used == 0xFFFFFFFFu)
+						return W_BAD;
+					used_all += used;
+					if (used_all > dn)
+						return W_BAD;
+				}
+				q += used_all;
+				if (q >= end)
+					return W_BAD;
+				const int64_t e0 = sink.seq_block(nseq, lit_pos, R, dst);
+				if (e0)
+					return e0;
+				// the stream is read through the sink's window, byte-wise (sequence sections are small
+				// next to the literals); bits come from the top of the last byte down
+				const uint64_t sb = q, sl = end - q;
+				const uint32_t lastb = f[end - 1];
+				if (!lastb)
+					return W_BAD;
+				int64_t bpos = 8ll * (int64_t) (sl - 1) + highbit(lastb); // bits left below the end mark
+				auto rd = [&](uint32_t n) -> uint32_t { // the n <= 32 bits below bpos, highest first; zeros below bit 0
+					uint32_t v = 0;
+					for (uint32_t i = 0; i < n; i++) {
+						bpos--;
+						uint32_t bit = 0;
+						if (bpos >= 0)
+							bit = (f[sb + (uint64_t) (bpos >> 3)] >> (bpos & 7)) & 1u;
+						v = (v << 1) | bit;
+					}
+					return v;
+				};
+				uint32_t stl = rd(k.st[0].log), sto = rd(k.st[1].log), stm = rd(k.st[2].log);
+				if (bpos < 0)
+					return W_BAD;
+				uint64_t lits_used = 0, out = dst;
+				for (uint32_t i = 0; i < nseq; i++) {
+					const uint32_t oc = k.st[1].sym[sto], mc = k.st[2].sym[stm], lc = k.st[0].sym[stl];
+					if (oc > 31)
+						return W_BAD;
+					uint32_t ofv = (oc ? (1u << oc) : 1u) + rd(oc);
+					uint32_t mb, lb;
+					const uint32_t mbase = ml_base(mc, &mb), lbase = ll_base(lc, &lb);
+					const uint32_t ml = mbase + rd(mb);
+					const uint32_t ll = lbase + rd(lb);
+					// repeat offsets (RFC 8878 3.1.1.5)
+					uint32_t off;
+					if (ofv > 3) {
+						off = ofv - 3;
+						rep[2] = rep[1];
+						rep[1] = rep[0];
+						rep[0] = off;
+					} else {
+						const uint32_t idx = ofv - (ll ? 1 : 0); // 0 .. 3
+						if (idx == 0) {
+							off = rep[0];
+						} else {
+							off = idx == 3 ? rep[0] - 1 : rep[idx];
+							if (idx != 1)
+								rep[2] = rep[1];
+							rep[1] = rep[0];
+							rep[0] = off;
+						}
+					}
+					if (bpos < 0 || off == 0)
+						return W_BAD;
+					lits_used += ll;
+					if (lits_used > R || off > out + ll || out + ll + ml > cap) // (off reaches at most to the frame's first byte)
+						return W_BAD;
+					sink.seq(i, ll, ml, off);
+					out += (uint64_t) ll + ml;
+					if (i + 1 < nseq) { // the states move on: literal lengths, match lengths, offsets
+						stl = k.st[0].nw[stl] + rd(k.st[0].nb[stl]);
+						stm = k.st[2].nw[stm] + rd(k.st[2].nb[stm]);
+						sto = k.st[1].nw[sto] + rd(k.st[1].nb[sto]);
+					}
+				}
+				if (bpos != 0)
+					return W_BAD;
+				// what is left of the literals follows the last match
+				const uint64_t tail = R - lits_used;
+				if (out + tail > cap)
+					return W_BAD;
+				sink.seq_end((uint32_t) tail);
+				produced = (uint32_t) (out + tail - dst);
+				lit_pos += R;
+			}
 			at = end;
-			dst += R;
+			dst += produced;
 		}
 		if (last)
 			break;

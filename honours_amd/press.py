@@ -75,7 +75,8 @@ HEADER_SYMBOLS = sorted(set(
      "press_hip_blow5_open", "press_hip_blow5_close", "press_hip_blow5_methods", "press_hip_blow5_next",
      "press_hip_blow5_last_error", "press_hip_blow5_next_records", "press_hip_blow5_create",
      "press_hip_blow5_write", "press_hip_blow5_finish",
-     "press_hip_shutdown", "press_hip_scratch_buffers", "press_hip_host_alloc", "press_hip_host_free"]))
+     "press_hip_shutdown", "press_hip_scratch_buffers", "press_hip_host_alloc", "press_hip_host_free",
+     "press_hip_zstd_host_frames"]))
 
 
 class PressError(RuntimeError):

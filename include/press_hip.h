@@ -265,13 +265,20 @@ int press_hip_depress_batch(int method, const uint8_t *in, const uint64_t *in_of
  *            zstd_svb_zd_depress_16 included; the BYTES are not libzstd's (they never were
  *            pinned: they depend on the libzstd version).  Size <= 9 + L + 3 * ceil(L / 128 KiB)
  *            for a content of L bytes, well inside press_hip_bound().
- *   depress  reads any single zstd frame of such a buffer: frames without sequences (all of
- *            the above, and libzstd's own when it found no matches) entirely on the device;
- *            frames with sequences, dictionaries or 12-bit Huffman tables are decompressed by
- *            libzstd on the host inside the call (one stream synchronisation per batch, only
- *            when such a frame is present).  n[r] is the room in samples; the count in the
- *            stream decides (press.c:1901).  Content checksums are not verified.
+ *   depress  reads any single zstd frame of such a buffer on the device: the frames above and
+ *            ZSTD_compress's own (the reference's streams, press.c:1462-1469) - Huffman literals,
+ *            FSE-coded sequences with all four table modes, repeat offsets - one wave per frame walks
+ *            the blocks, the literals are decoded in parallel, one wave per frame carries out its
+ *            sequences.  Only frames with a dictionary, a 12-bit Huffman table, more sequences than the
+ *            scratch takes, or several frames in one stream are decompressed by libzstd on the host
+ *            inside the call.  NOTE: a zstd depress batch always synchronises the stream once (the
+ *            count of such frames is read back), also when device_resident != 0.
+ *            n[r] is the room in samples; the count in the stream decides (press.c:1901).  Content
+ *            checksums are not verified.
  */
+/* frames the last zstd depress batch left to libzstd on the host (0 for this library's frames and for
+ * ZSTD_compress's) */
+uint32_t press_hip_zstd_host_frames(void);
 
 /*
  * Host buffers (device_resident == 0).  Ordinary (pageable) memory is copied through two page-locked

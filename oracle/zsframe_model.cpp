@@ -218,17 +218,49 @@ struct HostSink {
 	uint32_t sum(uint32_t v) const { return v; }
 	void sync() const {}
 	void fetch(uint8_t *dst, const uint8_t *src, uint32_t n) { memcpy(dst, src, n); }
-	void copy(uint64_t src, uint64_t dst, uint32_t n) { memcpy(out + dst, f + src, n); }
-	void fill(uint64_t src, uint64_t dst, uint32_t n) { memset(out + dst, f[src], n); }
+	// blocks with sequences: their literals go to a buffer of their own, the sequences copy from it
+	std::vector<uint8_t> lits;
+	uint64_t blk_lit = 0, blk_out = 0;
+	uint8_t *where(uint64_t dst, uint32_t n, bool lit)
+	{
+		if (!lit)
+			return out + dst;
+		if (lits.size() < dst + n + 1)
+			lits.resize(dst + n + 1);
+		return lits.data() + dst;
+	}
+	void copy(uint64_t src, uint64_t dst, uint32_t n, bool lit) { memcpy(where(dst, n, lit), f + src, n); }
+	void fill(uint64_t src, uint64_t dst, uint32_t n, bool lit) { memset(where(dst, n, lit), f[src], n); }
+	int64_t seq_block(uint32_t, uint64_t lit, uint32_t R, uint64_t dst)
+	{
+		(void) where(lit, R, true);
+		blk_lit = lit;
+		blk_out = dst;
+		return 0;
+	}
+	void seq(uint32_t, uint32_t ll, uint32_t ml, uint32_t off)
+	{
+		memcpy(out + blk_out, lits.data() + blk_lit, ll);
+		blk_lit += ll;
+		blk_out += ll;
+		for (uint32_t i = 0; i < ml; i++, blk_out++) // (byte by byte: a match may overlap itself)
+			out[blk_out] = out[blk_out - off];
+	}
+	void seq_end(uint32_t tail)
+	{
+		memcpy(out + blk_out, lits.data() + blk_lit, tail);
+		blk_out += tail;
+	}
 	int64_t tree(const uint8_t *w, uint32_t t)
 	{
 		tl = t;
 		zs::huf_build_dtable(w, t, dt);
 		return 0;
 	}
-	int64_t huf(uint64_t src, uint32_t cs, uint64_t dst, uint32_t R, bool four)
+	int64_t huf(uint64_t src, uint32_t cs, uint64_t dst, uint32_t R, bool four, bool lit)
 	{
 		const uint8_t *p = f + src;
+		uint8_t *out = where(dst, R, lit) - dst; // (so that out + dst is where the literals go)
 		if (!four)
 			return zs::huf_decode_stream(p, cs, dt, tl, out + dst, R) ? 0 : zs::W_BAD;
 		const uint32_t s1 = p[0] | (p[1] << 8), s2 = p[2] | (p[3] << 8), s3 = p[4] | (p[5] << 8);

@@ -234,8 +234,9 @@ def test_device_frames_small_slots():
 
 
 def test_model_reader_on_both_kinds_of_frames(model):
-    """zs::walk_frame on the host: this library's frames decode; libzstd's own decode when they
-    hold no sequences and are left to libzstd (-2) otherwise - never refused, never wrong"""
+    """zs::walk_frame on the host (the code the device walks frames with): this library's frames decode, and
+    so do libzstd's own at the reference's level 1 (press.h:275) and at levels 3 and 9 - sequences
+    included (FSE tables of all four modes, repeat offsets, overlapping matches)"""
     z = _zstd()
     oracle = _libs.oracle()
     m = ctypes.CDLL(MODEL_SO)
@@ -247,19 +248,30 @@ def test_model_reader_on_both_kinds_of_frames(model):
         out = np.zeros(cap + 64, dtype=np.uint8)
         r = m.zsm_decode(a.ctypes.data, len(f), out.ctypes.data, cap)
         return r, out[:max(r, 0)].tobytes()
-    own = host = 0
+    with_seq = 0
     for s in cases():
         buf = prezstd(oracle, s)
         r, b = dec(model(buf), len(buf))
         assert r == len(buf) and b == buf
         a = np.frombuffer(buf, dtype=np.uint8).copy()
         outz = np.zeros(len(buf) + len(buf) // 100 + 1024, dtype=np.uint8)
-        rz = z.ZSTD_compress(outz.ctypes.data, outz.size, a.ctypes.data, len(buf), 1)
-        r, b = dec(outz[:rz].tobytes(), len(buf))
-        assert r == -2 or (r == len(buf) and b == buf)
-        own += r >= 0
-        host += r == -2
-    assert own > 10 and host > 10  # both paths are exercised
+        for level in (1, 3, 9):
+            rz = z.ZSTD_compress(outz.ctypes.data, outz.size, a.ctypes.data, len(buf), level)
+            r, b = dec(outz[:rz].tobytes(), len(buf))
+            assert r == len(buf) and b == buf, (len(s), level, r)
+        with_seq += 1
+    # byte streams with long and overlapping matches, short offsets, RLE tables
+    rng = np.random.default_rng(5)
+    texts = [bytes(rng.integers(0, 4, 70000, dtype=np.uint8)), b"abcabcabd" * 9000, bytes(200000),
+             bytes(rng.integers(0, 256, 300, dtype=np.uint8)) * 700, b"x" * 5 + bytes(range(256)) * 600]
+    for t in texts:
+        a = np.frombuffer(t, dtype=np.uint8).copy()
+        outz = np.zeros(len(t) + len(t) // 100 + 1024, dtype=np.uint8)
+        for level in (1, 3, 9, 19):
+            rz = z.ZSTD_compress(outz.ctypes.data, outz.size, a.ctypes.data, len(t), level)
+            r, b = dec(outz[:rz].tobytes(), len(t))
+            assert r == len(t) and b == t, (len(t), level, r)
+    assert with_seq > 10
 
 
 def _libzstd_frames(z, oracle, reads, level=1, inner="svb_zd"):
@@ -298,16 +310,18 @@ def test_device_reads_its_own_frames(zm):
 @gpu
 @pytest.mark.parametrize("zm", sorted(KINDS))
 def test_device_reads_libzstd_frames(zm):
-    """the reference's own streams (libzstd level 1, press.h:275): blocks without sequences on
-    the device, the others through libzstd on the host - same samples either way"""
+    """the reference's own streams (ZSTD_compress level 1, press.h:275; levels 3 and 9 as well): decoded
+    entirely on the device - sequences included, no frame goes to libzstd on the host"""
     from honours_amd import press
     z = _zstd()
     oracle = _libs.oracle()
     reads = cases()
-    for level in (1, 3):
+    lib = press.load_library()
+    for level in (1, 3, 9):
         frames = _libzstd_frames(z, oracle, reads, level, KINDS[zm][0])
         keep = [k for k, f in enumerate(frames) if f is not None]
         back = press.depress_batch_host(zm, [frames[k] for k in keep], [len(reads[k]) for k in keep])
+        assert lib.press_hip_zstd_host_frames() == 0, level
         for k, b in zip(keep, back):
             assert b is not None and np.array_equal(b, reads[k]), "level %d case %d (n=%d)" % (level, k, len(reads[k]))
     # and the per-read symbol of the reference's interface reads a device-made frame
