@@ -1987,10 +1987,13 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, int ent, hipStream_t 
 	hipLaunchKernelGGL(k_ex_prefix, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a, fmt == EXF_EXZD ? 1 : 0);
 	hipLaunchKernelGGL(k_ex_list, dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	launch_ex_section(a, fmt, ent, s);
-	if (ent == 2) { // range coder: the one-byte values go to a temporary, one lane per read codes them
+	if (ent >= 2) { // range coder: the one-byte values go to a temporary, one lane (order 1: one workgroup) per read codes them
 		hipLaunchKernelGGL(k_low_encode_chunked, dim3(a.max_chunks), dim3(CWG), 0, s, a);
 		ktime_begin(0, s);
-		launch_rcs_encode(a, s);
+		if (ent == 2)
+			launch_rcs_encode(a, s);
+		else
+			launch_rcc_encode(a, s);
 		ktime_end(0, s);
 		return;
 	}

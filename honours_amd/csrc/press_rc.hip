@@ -246,6 +246,237 @@ __global__ __launch_bounds__(64) void k_rcs_decode(DecodeArgs a)
 	}
 }
 
+// ------------------------------------------------------------------ order 1: rcc_vbe21_zd
+//
+// rccsenc / rccsdec (rc_.c:181-205; press.c:5510-5580): the same bit coder, the 255 probabilities of a
+// byte chosen by the byte in front of it - 256 x 256 adaptive 16-bit predictors = 128 KiB of state per
+// read, which fits nowhere but a whole CU's LDS.  So: ONE READ PER WORKGROUP (one wave), the table in
+// LDS, reads handed out by a ticket to as many workgroups as there are CUs.  Every lane runs the same
+// interval arithmetic (uniform values); encoding, the eight predictors of a byte - their contexts are
+// known in advance - are fetched and updated by eight lanes at once, so the dependent chain is
+// arithmetic only; decoding, both candidates for the next context are fetched while a bit is decided.
+// What the format leaves: 256 reads in flight on the chip, each at one byte per few hundred cycles.
+
+namespace {
+constexpr uint32_t RCC_TAB = 65536; // predictors
+constexpr uint32_t RCC_WG = 64;
+
+__device__ __forceinline__ void rcc_init(uint16_t *mb)
+{
+	uint4 *m4 = reinterpret_cast<uint4 *>(mb);
+	const uint32_t v = (1u << 14) | (1u << 30);
+	for (uint32_t i = threadIdx.x; i < RCC_TAB / 8; i += RCC_WG)
+		m4[i] = make_uint4(v, v, v, v);
+	__syncthreads();
+}
+} // namespace
+
+__global__ __launch_bounds__(RCC_WG) void k_rcc_encode(BatchArgs a)
+{
+	__shared__ __attribute__((aligned(16))) uint16_t mb[RCC_TAB];
+	__shared__ uint32_t s_r;
+	const uint32_t lane = threadIdx.x;
+	for (;;) {
+		if (lane == 0)
+			s_r = atomicAdd(&a.ctl->ticket2, 1u);
+		__syncthreads();
+		const uint32_t r = s_r;
+		__syncthreads();
+		if (r >= a.nreads)
+			return;
+		const ReadMeta *m = a.meta + r;
+		if (m->status)
+			continue; // out_len = FAILED was written by k_ex_section
+		rcc_init(mb);
+		const uint64_t n = m->nlow;
+		const uint32_t head = m->hdr + m->seclen;
+		const uint8_t *in = a.low_tmp + a.off[r];
+		RcOut o;
+		o.out = a.out + a.out_off[r] + head;
+		o.cap = a.out_off[r + 1] - a.out_off[r] - head;
+		o.pos = 0;
+		o.failed = false;
+		uint64_t low = 0, range = ~0ull;
+		const long long giveup = (long long) (n * 255 / 256) - 8;
+		bool raw = false;
+		uint32_t cx = 0;
+		uint32_t grp = 0; // 64 input bytes, one per lane
+		for (uint64_t i = 0; i < n && !raw; i++) {
+			if ((i & 63) == 0)
+				grp = i + lane < n ? in[i + lane] : 0u;
+			const uint32_t byte = (uint32_t) __builtin_amdgcn_readlane((int) grp, __builtin_amdgcn_readfirstlane((int) (i & 63)));
+			const uint32_t x = 0x100u | byte;
+			uint16_t *row = mb + cx * 256u;
+			// lane k < 8: the predictor of bit k
+			const uint32_t node = x >> ((lane & 7u) + 1u);
+			const uint32_t pk = row[node];
+#pragma unroll
+			for (int k = 7; k >= 0; k--) {
+				if ((k & 1) && range < RC_TOP) {
+					range <<= 32;
+					if (lane == 0)
+						rc_put32(o, (uint32_t) (low >> 32));
+					else
+						o.pos += 4;
+					low <<= 32;
+				}
+				const uint32_t p = (uint32_t) __builtin_amdgcn_readlane((int) pk, k);
+				const uint64_t t = (range >> 15) * p, before = low;
+				if ((x >> k) & 1u) {
+					range = t;
+				} else {
+					range -= t;
+					low += t;
+				}
+				if (before > low && lane == 0)
+					rc_carry(o);
+			}
+			if (lane < 8) {
+				const uint32_t bit = (x >> lane) & 1u;
+				row[node] = (uint16_t) (bit ? pk + (32768u - pk + 31u) / 32u - 1u : pk - (pk >> 5));
+			}
+			cx = byte;
+			if ((long long) o.pos >= giveup)
+				raw = true; // rcutil_.h:161: stored instead
+		}
+		const bool failed0 = (bool) __shfl((int) o.failed, 0, 64);
+		if (raw) {
+			const bool fail = n > o.cap;
+			if (!fail)
+				for (uint64_t i = lane; i < n; i += RCC_WG)
+					o.out[i] = in[i];
+			if (lane == 0)
+				a.out_len[r] = fail ? ~0ull : (uint64_t) head + n;
+		} else if (lane == 0) {
+			o.failed = failed0;
+			if (range < RC_TOP) {
+				range <<= 32;
+				rc_put32(o, (uint32_t) (low >> 32));
+				low <<= 32;
+			}
+			const uint64_t before = low;
+			if (range > (1ull << 33)) {
+				low += 1ull << 32;
+				if (before > low)
+					rc_carry(o);
+				rc_put32(o, (uint32_t) (low >> 32));
+			} else {
+				low += 1;
+				if (before > low)
+					rc_carry(o);
+				rc_put32(o, (uint32_t) (low >> 32));
+				rc_put32(o, (uint32_t) low);
+			}
+			a.out_len[r] = o.failed ? ~0ull : (uint64_t) head + o.pos;
+		}
+		__syncthreads(); // the table is free again
+	}
+}
+
+__global__ __launch_bounds__(RCC_WG) void k_rcc_decode(DecodeArgs a)
+{
+	__shared__ __attribute__((aligned(16))) uint16_t mb[RCC_TAB];
+	__shared__ uint32_t s_r;
+	const uint32_t lane = threadIdx.x;
+	for (;;) {
+		if (lane == 0)
+			s_r = atomicAdd(&a.ctl->ticket2, 1u);
+		__syncthreads();
+		const uint32_t r = s_r;
+		__syncthreads();
+		if (r >= a.nreads)
+			return;
+		const ReadMeta *m = a.meta + r;
+		if (m->status)
+			continue;
+		rcc_init(mb);
+		const uint64_t n = m->nlow;
+		const uint32_t head = m->hdr + m->seclen;
+		const uint8_t *in = a.in + a.in_off[r] + head;
+		const uint64_t len = a.in_len[r] - head;
+		uint8_t *out = a.low + a.off[r];
+		uint64_t pos = 0, range = ~0ull, code = 0;
+		// bytes past the end of the stream read as zeros (the reference reads whatever follows)
+		auto get32 = [&]() -> uint32_t {
+			uint32_t w = 0;
+			if (pos + 4 <= len) {
+				__builtin_memcpy(&w, in + pos, 4);
+			} else {
+				for (int b = 0; b < 4; b++)
+					if (pos + b < len)
+						w |= (uint32_t) in[pos + b] << (8 * b);
+			}
+			pos += 4;
+			return w;
+		};
+		uint32_t wn = get32(); // the next word is always in flight before it is needed
+		auto next32 = [&]() -> uint32_t {
+			const uint32_t w = wn;
+			wn = get32();
+			return w;
+		};
+		code = next32();
+		code = (code << 32) | next32();
+		const uint16_t *row = mb;
+		uint32_t acc = 0; // four decoded bytes
+		for (uint64_t i = 0; i < n; i++) {
+			uint32_t x = 1;
+			uint32_t p = row[1];
+#pragma unroll
+			for (int k = 7; k >= 0; k--) {
+				// both candidates for the next context while this bit is being decided
+				uint32_t c0 = 0, c1 = 0;
+				if (k) {
+					c0 = row[2 * x];
+					c1 = row[2 * x + 1];
+				}
+				if ((k & 1) && range < RC_TOP) {
+					range <<= 32;
+					code = (code << 32) | next32();
+				}
+				const uint64_t t = (range >> 15) * p;
+				uint16_t *slot = const_cast<uint16_t *>(row) + x;
+				if (code < t) {
+					range = t;
+					if (lane == 0)
+						*slot = (uint16_t) (p + (32768u - p + 31u) / 32u - 1u);
+					x = 2 * x + 1;
+					p = c1;
+				} else {
+					range -= t;
+					code -= t;
+					if (lane == 0)
+						*slot = (uint16_t) (p - (p >> 5));
+					x = 2 * x;
+					p = c0;
+				}
+			}
+			acc |= (x & 0xFFu) << (8 * ((uint32_t) i & 3u));
+			if (((uint32_t) i & 3u) == 3u || i + 1 == n) {
+				if (lane == 0)
+					for (uint32_t b = 0; b <= ((uint32_t) i & 3u); b++)
+						out[(i & ~3ull) + b] = (uint8_t) (acc >> (8 * b));
+				acc = 0;
+			}
+			row = mb + 256u * (x & 0xFFu); // rc_.c:199: the byte just decoded is the next context
+			// (lane 0's stores to the table and every lane's later loads are DS operations of one wave: in order)
+		}
+		__syncthreads();
+	}
+}
+
+void launch_rcc_encode(const BatchArgs &a, hipStream_t s)
+{
+	(void) hipMemsetAsync(&a.ctl->ticket2, 0, 4, s);
+	hipLaunchKernelGGL(k_rcc_encode, dim3(a.nreads < 256u ? a.nreads : 256u), dim3(RCC_WG), 0, s, a);
+}
+
+void launch_rcc_decode(const DecodeArgs &a, hipStream_t s)
+{
+	(void) hipMemsetAsync(&a.ctl->ticket2, 0, 4, s);
+	hipLaunchKernelGGL(k_rcc_decode, dim3(a.nreads < 256u ? a.nreads : 256u), dim3(RCC_WG), 0, s, a);
+}
+
 void launch_rcs_encode(const BatchArgs &a, hipStream_t s)
 {
 	hipLaunchKernelGGL(k_rcs_encode, dim3((a.nreads + 63) / 64), dim3(64), 0, s, a);

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64) void k_ex_parse_fill_vbe21(DecodeArgs a)
 
 void launch_ex_section(const BatchArgs &a, int fmt, int ent, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_ex_section, dim3(a.nreads), dim3(64), 0, s, a, fmt, ent == 1 ? 2 : ent == 2 ? 3 : 0);
+	hipLaunchKernelGGL(k_ex_section, dim3(a.nreads), dim3(64), 0, s, a, fmt, ent == 1 ? 2 : ent >= 2 ? 3 : 0);
 	if (fmt == EXF_VBE21)
 		hipLaunchKernelGGL(k_ex_fill_vbe21, dim3(a.nreads), dim3(64), 0, s, a);
 }
@@ -459,13 +459,15 @@ void launch_ex_section(const BatchArgs &a, int fmt, int ent, hipStream_t s)
 // dominant kernel of those methods)
 void launch_ex_parse_huff(const DecodeArgs &a, int fmt, int ent, hipStream_t s)
 {
-	hipLaunchKernelGGL(k_ex_parse, dim3(a.nreads), dim3(64), 0, s, a, fmt, ent == 2 ? 3 : ent);
+	hipLaunchKernelGGL(k_ex_parse, dim3(a.nreads), dim3(64), 0, s, a, fmt, ent >= 2 ? 3 : ent);
 	if (fmt == EXF_VBE21)
 		hipLaunchKernelGGL(k_ex_parse_fill_vbe21, dim3(a.nreads), dim3(64), 0, s, a);
 	if (ent) {
 		ktime_begin(1, s);
 		if (ent == 2)
 			launch_rcs_decode(a, s);
+		else if (ent == 3)
+			launch_rcc_decode(a, s);
 		else
 			launch_huff_decode(a, a.huf_minlen, s);
 		ktime_end(1, s);

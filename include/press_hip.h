@@ -136,6 +136,11 @@ int shuffman_vbsse21_zd_depress_16(huffman_node *root, uint8_t *in, uint64_t nin
 uint64_t rc_vbe21_zd_bound_16(uint32_t nin);
 void rc_vbe21_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
 void rc_vbe21_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+/* ---- vbe21 + order-1 adaptive range coder (TurboRC rccsenc / rccsdec, rc_.c:181): press.h (press.c:5510-5580).
+ * Same calling shape as rc_vbe21_zd. ---- */
+uint64_t rcc_vbe21_zd_bound_16(uint32_t nin);
+void rcc_vbe21_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+void rcc_vbe21_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
 
 /* ---- ex-zd v0: press.h:960-964 (press.c:8461-8500 over ex_zd.c:403,495) ---- */
 uint64_t hasgam_vbsse21_zdq_bound_16(uint32_t nin);
@@ -182,7 +187,8 @@ enum press_hip_method {
 	PRESS_HIP_ZSTD_HASGAM_ZDQ  = 14, /* zstd(ex-zd): as method 3 */
 	PRESS_HIP_SLOW5_SVB_ZD     = 15, /* BLOW5's signal codec (section 3) */
 	PRESS_HIP_RC_VBE21_ZD      = 16, /* vbe21 + order-0 range coder: one read per lane (serial format) */
-	PRESS_HIP_NMETHODS         = 17
+	PRESS_HIP_RCC_VBE21_ZD     = 17, /* vbe21 + order-1 range coder: one read per workgroup, its 128 KiB of state in LDS */
+	PRESS_HIP_NMETHODS         = 18
 };
 
 #define PRESS_HIP_OK        0

@@ -694,6 +694,7 @@ uint64_t po_bound(int method, uint32_t n)
 	case PM_SHUFF_VBE21_ZD: case PM_SHUFF_VBBE21_ZD: case PM_SHUFF_VBSBE21_ZD:
 	case PM_SHUFF_VBSSE21_ZD: return vb_zd_bound(n);                           /* press.c:3411,4409 */
 	case PM_RC_VBE21_ZD:      return vb_zd_bound(n);                           /* press.c:5422 */
+	case PM_RCC_VBE21_ZD:     return vb_zd_bound(n);                           /* press.c:5510 */
 	case PM_HASGAM_ZDQ:       return svb32_bound((uint32_t) vb_zd_bound(n));   /* press.c:8461 */
 	case PM_ZSTD_HASGAM_ZDQ:  return zstd_bound_(svb32_bound((uint32_t) vb_zd_bound(n)));
 	/* slow5_press.c:1037: __slow5_streamvbyte_max_compressedbytes(n) (streamvbyte.h:31, no padding) + the u32 count */
@@ -772,28 +773,35 @@ static void rc_bit(struct rc_enc *c, uint16_t *p, unsigned bit)
 		rc_carry(c);
 }
 
-/* out must have room for n + n/2 + 64 bytes; returns the stream length */
-uint64_t po_rcs_encode(const uint8_t *in, uint64_t n, uint8_t *out)
+/* out must have room for n + n/2 + 64 bytes; returns the stream length.
+ * order1 (rccsenc, rc_.c:181-193): the same bit coder, the 255 probabilities of a byte chosen by the
+ * byte in front of it (256 x 256 predictors, the first byte under context 0). */
+static uint64_t rc_encode(const uint8_t *in, uint64_t n, uint8_t *out, int order1)
 {
 	struct rc_enc c = { 0, ~(uint64_t) 0, out, 0 };
-	uint16_t mb[256];
+	uint16_t *mb = malloc((order1 ? 65536u : 256u) * sizeof *mb);
 	uint64_t i;
 	const int64_t giveup = (int64_t) (n * 255 / 256) - 8;
 	int k;
-	for (k = 0; k < 256; k++)
+	unsigned cx = 0;
+	for (k = 0; k < (order1 ? 65536 : 256); k++)
 		mb[k] = 1u << 14;
 	for (i = 0; i < n; i++) {
 		const unsigned x = 0x100u | in[i];
+		uint16_t *row = mb + (order1 ? cx * 256u : 0u);
 		for (k = 7; k >= 0; k--) {
 			if (k & 1)
 				rc_norm(&c);
-			rc_bit(&c, &mb[x >> (k + 1)], (x >> k) & 1u);
+			rc_bit(&c, &row[x >> (k + 1)], (x >> k) & 1u);
 		}
+		cx = in[i];
 		if ((int64_t) c.pos >= giveup) {
 			memcpy(out, in, n);
+			free(mb);
 			return n;
 		}
 	}
+	free(mb);
 	rc_norm(&c);
 	{
 		const uint64_t before = c.low;
@@ -812,6 +820,8 @@ uint64_t po_rcs_encode(const uint8_t *in, uint64_t n, uint8_t *out)
 	}
 	return c.pos;
 }
+uint64_t po_rcs_encode(const uint8_t *in, uint64_t n, uint8_t *out) { return rc_encode(in, n, out, 0); }
+uint64_t po_rccs_encode(const uint8_t *in, uint64_t n, uint8_t *out) { return rc_encode(in, n, out, 1); }
 
 static uint32_t rc_get32(const uint8_t *in, uint64_t len, uint64_t pos)
 {
@@ -824,14 +834,14 @@ static uint32_t rc_get32(const uint8_t *in, uint64_t len, uint64_t pos)
 }
 
 /* decodes n bytes; bytes past `len` read as zeros (the reference reads whatever follows) */
-void po_rcs_decode(const uint8_t *in, uint64_t len, uint64_t n, uint8_t *out)
+static void rc_decode(const uint8_t *in, uint64_t len, uint64_t n, uint8_t *out, int order1)
 {
 	uint64_t range = ~(uint64_t) 0, code = 0, pos = 0, i;
-	uint16_t mb[256];
+	uint16_t *mb0 = malloc((order1 ? 65536u : 256u) * sizeof *mb0), *mb = mb0;
 	int k;
 #define RC_GET32() rc_get32(in, len, pos); pos += 4
-	for (k = 0; k < 256; k++)
-		mb[k] = 1u << 14;
+	for (k = 0; k < (order1 ? 65536 : 256); k++)
+		mb0[k] = 1u << 14;
 	for (k = 0; k < 2; k++) {
 		const uint32_t w = RC_GET32();
 		code = (code << 32) | w;
@@ -859,14 +869,19 @@ void po_rcs_decode(const uint8_t *in, uint64_t len, uint64_t n, uint8_t *out)
 			}
 		}
 		out[i] = (uint8_t) x;
+		if (order1)
+			mb = mb0 + 256u * (uint8_t) x; /* rc_.c:199: the byte just decoded is the next context */
 	}
+	free(mb0);
 #undef RC_GET32
 }
+void po_rcs_decode(const uint8_t *in, uint64_t len, uint64_t n, uint8_t *out) { rc_decode(in, len, n, out, 0); }
+void po_rccs_decode(const uint8_t *in, uint64_t len, uint64_t n, uint8_t *out) { rc_decode(in, len, n, out, 1); }
 
 static enum exfmt exfmt_of(int method)
 {
 	switch (method) {
-	case PM_VBE21_ZD: case PM_SHUFF_VBE21_ZD: case PM_RC_VBE21_ZD: return EX_VBE21;
+	case PM_VBE21_ZD: case PM_SHUFF_VBE21_ZD: case PM_RC_VBE21_ZD: case PM_RCC_VBE21_ZD: return EX_VBE21;
 	case PM_VBBE21_ZD: case PM_SHUFF_VBBE21_ZD:   return EX_VBBE21;
 	case PM_VBSBE21_ZD: case PM_SHUFF_VBSBE21_ZD: return EX_VBSBE21;
 	case PM_VBSSE21_ZD: case PM_SHUFF_VBSSE21_ZD: return EX_VBSSE21;
@@ -911,9 +926,9 @@ static int vb_family_press(int method, const int16_t *in, uint32_t n, uint8_t *o
 	put_u16(out, z[0]);
 	memcpy(out + 2, sec, seclen);
 	o = 2 + seclen;
-	if (method == PM_RC_VBE21_ZD) { /* press.c:5427: the one-byte values through rcsenc */
+	if (method == PM_RC_VBE21_ZD || method == PM_RCC_VBE21_ZD) { /* press.c:5427 / :5547: the one-byte values through rcsenc / rccsenc */
 		uint8_t *tmp = malloc((size_t) nlow + nlow / 2 + 64);
-		const uint64_t rl = po_rcs_encode(low, nlow, tmp);
+		const uint64_t rl = rc_encode(low, nlow, tmp, method == PM_RCC_VBE21_ZD);
 		if (o + rl > cap) {
 			free(tmp);
 			goto done;
@@ -961,12 +976,12 @@ static int vb_family_depress(int method, const uint8_t *in, uint64_t nbytes, uin
 	}
 	z = malloc(((size_t) n + 1) * sizeof *z);
 	z[0] = get_u16(in);
-	if (method == PM_RC_VBE21_ZD) { /* press.c:5465: n is the exact sample count, so the byte count is known */
+	if (method == PM_RC_VBE21_ZD || method == PM_RCC_VBE21_ZD) { /* press.c:5465 / :5573: n is the exact sample count, so the byte count is known */
 		if ((uint64_t) e.n + 1 > n)
 			goto done;
 		nlow = (uint64_t) n - 1 - e.n;
 		low = malloc((size_t) nlow + 1);
-		po_rcs_decode(in + 2 + seclen, nbytes - 2 - seclen, nlow, low);
+		rc_decode(in + 2 + seclen, nbytes - 2 - seclen, nlow, low, method == PM_RCC_VBE21_ZD);
 		lowp = low;
 	} else if (is_shuff(method)) {
 		uint32_t got = 0;
@@ -1178,7 +1193,7 @@ int po_press(int method, const int16_t *in, uint32_t n, uint8_t *out, uint64_t *
 	case PM_VBE21_ZD: case PM_VBBE21_ZD: case PM_VBSBE21_ZD: case PM_VBSSE21_ZD:
 	case PM_SHUFF_VBE21_ZD: case PM_SHUFF_VBBE21_ZD: case PM_SHUFF_VBSBE21_ZD:
 	case PM_SHUFF_VBSSE21_ZD:
-	case PM_RC_VBE21_ZD:
+	case PM_RC_VBE21_ZD: case PM_RCC_VBE21_ZD:
 		return vb_family_press(method, in, n, out, nout);
 	case PM_SLOW5_SVB_ZD: {
 		/* slow5_press.c:1054 ptr_compress_svb_zd: samples widened to int32, zig-zag delta in 32 bits
@@ -1233,7 +1248,7 @@ int po_depress(int method, const uint8_t *in, uint64_t nbytes, uint32_t n,
 	case PM_VBE21_ZD: case PM_VBBE21_ZD: case PM_VBSBE21_ZD: case PM_VBSSE21_ZD:
 	case PM_SHUFF_VBE21_ZD: case PM_SHUFF_VBBE21_ZD: case PM_SHUFF_VBSBE21_ZD:
 	case PM_SHUFF_VBSSE21_ZD:
-	case PM_RC_VBE21_ZD:
+	case PM_RC_VBE21_ZD: case PM_RCC_VBE21_ZD:
 		return vb_family_depress(method, in, nbytes, n, out, nout);
 	case PM_SLOW5_SVB_ZD: {
 		/* slow5_press.c:1110 ptr_depress_svb_zd -> :1085 ptr_depress_svb: the count comes from

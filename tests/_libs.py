@@ -23,6 +23,7 @@ METHODS = {
     "shuffman_vbsse21_zd": 12, "hasgam_vbsse21_zdq": 13, "zstd_hasgam_vbsse21_zdq": 14,
     "slow5_svb_zd": 15,  # BLOW5's signal codec (slow5lib svb-zd), SURVEY 8f-2
     "rc_vbe21_zd": 16,   # vbe21 + TurboRC order-0 range coder, SURVEY 8f-1
+    "rcc_vbe21_zd": 17,  # vbe21 + TurboRC order-1 range coder, SURVEY 8f-1
 }
 DETERMINISTIC = [m for m in METHODS if not m.startswith("zstd_")]
 

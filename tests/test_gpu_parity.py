@@ -54,7 +54,7 @@ def check_read(oracle, m, sig, want=None):
     if m in DET:
         assert got == want, (m, n, len(got), len(want))
     ret, back = press.depress(m, got, n)
-    if m == "rc_vbe21_zd":
+    if m in ("rc_vbe21_zd", "rcc_vbe21_zd"):
         # reference quirk (TurboRC rcutil_.h:161): once the coder's output reaches n*255/256 - 8 bytes it
         # stores the bytes raw, and nothing tells rcsdec - such reads (a few dozen samples) are outside
         # the reference's lossless domain; there the GPU must still do what the reference's decoder does

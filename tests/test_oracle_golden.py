@@ -162,7 +162,7 @@ def test_oracle_vs_reference_fuzz(oracle):
                 assert oracle.bound(m, n) == ref.bound(m, n)
                 if rr == 0:
                     dr, dd = oracle.depress(m, rc, n)
-                    if m == "rc_vbe21_zd":
+                    if m in ("rc_vbe21_zd", "rcc_vbe21_zd"):
                         # TurboRC stores tiny / incompressible inputs raw (rcutil_.h:161) and its decoder
                         # cannot tell: such streams are outside the reference's lossless domain (its own
                         # decoder may even abort on them), so only the encoder is compared there
