@@ -153,36 +153,32 @@ __device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint16_t
 		int32_t Lm = (int32_t) L - HUF_LUT_BITS; // every code of a look-up starts below L while p <= Lm
 		uint32_t j = p >> 5;
 		uint32_t w0 = col[j * 64], w1 = col[(j + 1) * 64];
-		const uint32_t *pf = col + (j + 2) * 64;
 		for (;;) {
 			const bool act = (int32_t) p <= Lm;
 			if (!any64(act))
 				break;
-			const uint32_t w2 = *pf; // (the row behind the last column keeps this read inside the array)
-			const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p); // shift = p & 31
-			const uint32_t e = mlut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
-			uint32_t tot = e & 15u, n = (e >> 4) & 15u;
-			bool ok = act;
-			if (any64(act && (e & 0x8000u))) {
-				if (act && (e & 0x8000u)) {
+			if (act) { // (exec-masked body: the lanes that are done do nothing)
+				const uint32_t w2 = col[(j + 2) * 64]; // (the row behind the last column keeps this read inside the array)
+				const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p); // shift = p & 31
+				const uint32_t e = mlut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
+				uint32_t tot = e & 15u, n = (e >> 4) & 15u;
+				if (e & 0x8000u) { // rare (one code in 200): a long code, or none
 					tot = long_len(e, wnd);
 					n = 1;
 					if (tot == 0 || p + tot > L) { // no code, or it ends behind the limit:
-						ok = false;            // the careful loop decides
+						tot = n = 0;           // the careful loop decides
 						Lm = -1;
 					}
 				}
-			}
-			if (ok) {
 				p += tot;
 				c += n;
+				const uint32_t jn = p >> 5; // a step crosses at most one dword
+				if (jn != j) {
+					w0 = w1;
+					w1 = w2;
+				}
+				j = jn;
 			}
-			const uint32_t jn = p >> 5; // a step crosses at most one dword
-			const bool st = jn != j;
-			w0 = st ? w1 : w0;
-			w1 = st ? w2 : w1;
-			pf = col + (jn + 2) * 64;
-			j = jn;
 		}
 	}
 	for (;;) {
@@ -512,37 +508,35 @@ __device__ __forceinline__ void emit_codes(const uint32_t *col, const uint32_t *
 		const int32_t qm = (int32_t) nmine - 2;
 		uint32_t j = p >> 5;
 		uint32_t w0 = col[j * 64], w1 = col[(j + 1) * 64];
-		const uint32_t *pf = col + (j + 2) * 64;
 		for (;;) {
 			const bool act = (int32_t) p <= Lm && (int32_t) q <= qm;
 			if (!any64(act))
 				break;
-			const uint32_t w2 = *pf; // (the row behind the last column keeps this read inside the array)
-			const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p);
-			uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
-			bool ok = act;
-			if (any64(act && e >= HUF_LONG)) {
-				if (act && e >= HUF_LONG) {
+			if (act) { // (exec-masked body: the lanes that are done do nothing)
+				const uint32_t w2 = col[(j + 2) * 64]; // (the row behind the last column keeps this read inside the array)
+				const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p);
+				uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
+				if (e >= HUF_LONG) { // rare (one code in 200): longer than 12 bits
 					e = long_entry(e, wnd);
 					if (e == 0 || p + ((e >> 8) & 0x1Fu) > L) {
-						ok = false;
-						Lm = -1;
+						e = 0;
+						Lm = -1; // the careful loop decides
 					}
 				}
+				if (e) {
+					wp[q] = (uint8_t) e;
+					if (e & HUF_TWO)
+						wp[q + 1] = (uint8_t) (e >> 16);
+					q += 1u + ((e >> 29) & 1u);
+					p += (e >> 8) & 0x1Fu;
+				}
+				const uint32_t jn = p >> 5;
+				if (jn != j) {
+					w0 = w1;
+					w1 = w2;
+				}
+				j = jn;
 			}
-			if (ok) {
-				wp[q] = (uint8_t) e;
-				if (e & HUF_TWO)
-					wp[q + 1] = (uint8_t) (e >> 16);
-				q += 1u + ((e >> 29) & 1u);
-				p += (e >> 8) & 0x1Fu;
-			}
-			const uint32_t jn = p >> 5;
-			const bool st = jn != j;
-			w0 = st ? w1 : w0;
-			w1 = st ? w2 : w1;
-			pf = col + (jn + 2) * 64;
-			j = jn;
 		}
 	}
 	for (;;) { // the careful loop: the last codes of the subsequence / of the quota
