@@ -41,7 +41,7 @@ def run_pass(method, counter, tag):
         k = r["Kernel_Name"]
         if "ph::" not in k:
             continue
-        k = k.split("(")[0].replace("void ph::", "").replace("ph::", "")
+        k = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ph::", "").replace("ph::", "")
         agg[k] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
     return {k: v / len(disp[k]) for k, v in agg.items()}, {k: len(v) for k, v in disp.items()}
