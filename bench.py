@@ -80,8 +80,8 @@ def kernel_own_bytes(m, which, raw, comp, nsamp):
     the kernels of a multi-kernel pipeline hand intermediates to each other through HBM."""
     if m.startswith("shuffman"):
         # encode: samples in, payload out; decode (k_huf_sync .. k_huf_emit, timed together): payload in,
-        # the one-byte values out (k_low_decode_chunked<true> then reads them and writes the samples)
-        return raw + comp if which == 0 else comp + nsamp
+        # samples out (k_huf_emit writes them itself: the one-byte values never reach HBM)
+        return raw + comp
     if m.startswith("zstd"):
         # k_zs_encode: inner stream (1.25 B/sample) in, frame out; k_zs_hdecode: frame in, literals out
         inner = nsamp * 5 // 4

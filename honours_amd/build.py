@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpress_hip.so")
 SOURCES = ["press_sections.hip", "press_chunked.hip", "press_huffman.hip", "press_rc.hip", "press_zstd.hip", "press_abi.hip", "blow5_reader.cpp"]
-HEADERS = ["press_internal.h", os.path.join("..", "..", "include", "press_hip.h")]
+HEADERS = ["press_internal.h", "press_packed.h", "zs_table.h", os.path.join("..", "..", "include", "press_hip.h")]
 
 
 def _stale():

@@ -206,6 +206,9 @@ int exfmt_of(int m)
 }
 
 // ---- static Huffman table -> device form ----
+// the delta a one-byte value stands for (zig-zag undone): 0, -1, 1, -2, ... -128
+static inline int32_t unzz8(uint32_t z) { return (int32_t) (z >> 1) ^ -(int32_t) (z & 1u); }
+
 int upload_table(const uint32_t len[256], const uint64_t bits[256])
 {
 	if (g.have_table && !memcmp(len, g.tlen, sizeof g.tlen) && !memcmp(bits, g.tbits, sizeof g.tbits))
@@ -290,8 +293,10 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 			for (uint32_t i = rest; i < (1u << depth[id]); i += 1u << rl)
 				h.lut2[h.l2off[id] + i] = (uint16_t) (s | (len[s] << 8));
 		}
-		for (int i = 0; i < HUF_L2_ENTRIES; i++)
-			h.l2len[i] = h.lut2[i] == 0xFFFFu ? (uint8_t) 0xFF : (uint8_t) (h.lut2[i] >> 8);
+		for (int i = 0; i < HUF_L2_ENTRIES; i++) {
+			const uint32_t e2 = h.lut2[i];
+			h.l2ld[i] = e2 == 0xFFFFu ? (uint16_t) 0xFFFFu : (uint16_t) ((e2 >> 8) | ((unzz8(e2 & 0xFFu) & 0xFFu) << 8));
+		}
 	}
 	// two-symbol table
 	for (uint32_t i = 0; i < (1u << HUF_LUT_BITS); i++) {
@@ -302,36 +307,42 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 			const uint32_t id = e1 & 0xFFu;
 			h.lut32[i] = HUF_LONG | ((uint32_t) h.l2bits[id] << 12) | h.l2off[id];
 		} else {
-			const uint32_t s1 = e1 & 0xFFu, l1 = e1 >> 8;
+			// (the parallel decoder stages the delta a symbol stands for, not the symbol)
+			const uint32_t s1 = (uint32_t) unzz8(e1 & 0xFFu) & 0xFFu, l1 = e1 >> 8;
 			uint32_t v = s1 | (l1 << 8) | (l1 << 24);
 			const uint32_t rest = (uint32_t) HUF_LUT_BITS - l1;
 			const uint16_t e2 = h.lut[i >> l1]; // the upper bits are zeros, not stream bits:
 			if (e2 != 0xFFFFu && !(e2 & 0x8000u) && (uint32_t) (e2 >> 8) <= rest) // only a code that fits counts
-				v = s1 | ((l1 + (e2 >> 8)) << 8) | ((uint32_t) (e2 & 0xFFu) << 16) | (l1 << 24) | HUF_TWO;
+				v = s1 | ((l1 + (e2 >> 8)) << 8) | (((uint32_t) unzz8(e2 & 0xFFu) & 0xFFu) << 16) | (l1 << 24) | HUF_TWO;
 			h.lut32[i] = v;
 		}
 	}
-	// every whole code that fits in the first HUF_LUT_BITS bits, lengths only (k_huf_sync)
+	// every whole code that fits in the first HUF_LUT_BITS bits, lengths and deltas (k_huf_sync)
 	for (uint32_t i = 0; i < (1u << HUF_LUT_BITS); i++) {
 		uint32_t pos = 0, n = 0, len1 = 0;
+		int32_t d1 = 0, dsum = 0;
 		for (;;) {
 			const uint16_t e1 = h.lut[i >> pos]; // the upper bits are zeros, not stream bits:
 			if (e1 == 0xFFFFu || (e1 & 0x8000u) || pos + (uint32_t) (e1 >> 8) > (uint32_t) HUF_LUT_BITS)
 				break; // only a code that fits counts
-			if (!n)
+			const int32_t d = (int32_t) unzz8(e1 & 0xFFu);
+			if (!n) {
 				len1 = e1 >> 8;
+				d1 = d;
+			}
+			dsum += d;
 			pos += e1 >> 8;
 			n++;
-			if (pos == (uint32_t) HUF_LUT_BITS || n == 15)
+			if (pos == (uint32_t) HUF_LUT_BITS || n == HUF_M_MAXN)
 				break;
 		}
 		const uint16_t e0 = h.lut[i];
 		if (n)
-			h.mlut[i] = (uint16_t) (pos | (n << 4) | (len1 << 8));
-		else if (e0 != 0xFFFFu && (e0 & 0x8000u)) // long code: second-level table of lengths (HUF_MLONG)
-			h.mlut[i] = (uint16_t) (0x8000u | ((uint32_t) h.l2bits[e0 & 0xFFu] << 11) | (h.l2off[e0 & 0xFFu] >> 1));
+			h.mlut[i] = pos | (n << 4) | (len1 << 8) | (((uint32_t) d1 & 0xFFu) << 12) | (((uint32_t) dsum & 0x7FFu) << 20);
+		else if (e0 != 0xFFFFu && (e0 & 0x8000u)) // long code: second-level table of lengths and deltas
+			h.mlut[i] = HUF_MLONG | (uint32_t) h.l2off[e0 & 0xFFu] | ((uint32_t) h.l2bits[e0 & 0xFFu] << 12);
 		else
-			h.mlut[i] = (uint16_t) 0xFFFFu;
+			h.mlut[i] = 0xFFFFFFFFu;
 	}
 	if (!ncoded)
 		return fail(PRESS_HIP_EARG, "Huffman table: no symbol has a code");

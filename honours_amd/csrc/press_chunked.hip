@@ -25,6 +25,7 @@
 // streamvbyte_encode.c:70, streamvbyte_decode.c:62; press.c:1573-1611, 1678-1694.
 
 #include "press_internal.h"
+#include "press_packed.h"
 
 namespace ph {
 
@@ -45,7 +46,6 @@ constexpr uint64_t CFAIL64 = ~0ull;
 constexpr uint32_t CFAIL32 = 0xFFFFFFFFu;
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // wave-uniform values: tell the compiler (scalar registers, scalar branches)
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t) __builtin_amdgcn_readfirstlane((int) v); }
@@ -510,47 +510,6 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 // expanded twice (once to sum the deltas, once to store) - ALU is cheap, registers are
 // what bounds the number of chunks in flight per CU.
 
-// inclusive wave scan with DPP (row_shr 1,2,4,8 inside rows of 16, then row_bcast 15 / 31)
-__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v)
-{
-	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, true); // row_shr:1
-	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, true); // row_shr:2
-	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, true); // row_shr:4
-	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, true); // row_shr:8
-	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
-	v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2,3
-	return v;
-}
-
-// inverse zig-zag of two packed 16-bit values (trans.c:80)
-__device__ __forceinline__ uint32_t unzz_pair(uint32_t z)
-{
-	const u16x2 v = __builtin_bit_cast(u16x2, z);
-	const u16x2 one = { 1, 1 };
-	const u16x2 zero = { 0, 0 };
-	const u16x2 r = (v >> one) ^ (zero - (v & one));
-	return __builtin_bit_cast(uint32_t, r);
-}
-
-__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b)
-{
-	return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
-}
-
-// running sums of the 8 packed deltas of a lane: d[q] = [s(2q), s(2q+1)]; returns the total
-__device__ __forceinline__ uint32_t lane_prefix8(uint32_t d[4])
-{
-	uint32_t run = 0; // previous total in both halves
-#pragma unroll
-	for (int q = 0; q < 4; q++) {
-		uint32_t t = d[q] + (d[q] << 16);             // [a, a+b]
-		t = pk_add16(t, run);
-		d[q] = t;
-		run = __builtin_amdgcn_perm(t, t, 0x03020302); // broadcast the high half
-	}
-	return run >> 16;
-}
-
 // key bits (svb16) / 2-bit codes (svb32) of the 8 samples at i0, masked to the valid ones
 template <bool KEY2>
 __device__ __forceinline__ uint32_t load_key(const uint8_t *in, uint32_t i0, uint32_t n)
@@ -619,15 +578,6 @@ __device__ __forceinline__ uint32_t gather_slow(const uint8_t *in, const uint8_t
 __device__ __forceinline__ uint32_t unzz_pair_hib(uint32_t z, uint32_t hib, int q)
 {
 	return unzz_pair(z) ^ ((((hib >> (2 * q)) & 1u) << 15) | (((hib >> (2 * q + 1)) & 1u) << 31));
-}
-
-// 8 one-byte values -> 4 packed pairs
-__device__ __forceinline__ void expand8(uint2 dd, uint32_t v[4])
-{
-	v[0] = __builtin_amdgcn_perm(0, dd.x, 0x0c010c00);
-	v[1] = __builtin_amdgcn_perm(0, dd.x, 0x0c030c02);
-	v[2] = __builtin_amdgcn_perm(0, dd.y, 0x0c010c00);
-	v[3] = __builtin_amdgcn_perm(0, dd.y, 0x0c030c02);
 }
 
 // ---- key scan: the exception counts depend on the key bytes only (n/8 bytes, 4 % of the
@@ -1593,17 +1543,20 @@ __global__ __launch_bounds__(CWG) void k_huff_encode_chunked(BatchArgs a)
 // chunk finds its place in the stream by binary search - only the running sample value
 // needs the look-back chain.
 
-// chunk table from the parsed streams: n = 1 + nlow + nex samples per read
+// chunk table from the parsed streams: n = 1 + nlow + nex samples per read (hread: the Huffman decoder's
+// per-read record - reads it has finished itself get no chunks)
 __global__ __launch_bounds__(256) void k_chunk_prep_meta(const uint64_t *off, const uint64_t *in_off,
 							 const ReadMeta *meta, uint32_t nreads, ChunkDesc *chunks,
 							 uint64_t *gran, ChunkCtl *ctl, uint32_t max_chunks,
-							 uint32_t *out_n)
+							 uint32_t *out_n, const uint32_t *hread)
 {
 	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
 	uint32_t n = 0, nch = 0;
 	if (r < nreads && !meta[r].status) {
 		n = 1u + meta[r].nlow + meta[r].nex;
 		nch = (n + CHUNK - 1) / CHUNK;
+		if (hread && (hread[2 * r + 1] & HUF_FUSED))
+			nch = 0; // k_huf_emit wrote this read's samples already
 	}
 	const uint32_t inc = wave_incl_scan32(nch);
 	uint32_t base = 0;
@@ -1703,6 +1656,8 @@ __device__ __forceinline__ void gather_low(const uint8_t *low, uint32_t nlow, co
 	}
 }
 
+// HUFF: the one-byte values come from a.low (entropy decoders); the grid may then be smaller than the
+// number of chunks (workgroups keep taking tickets)
 template <bool HUFF>
 __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 {
@@ -1719,6 +1674,7 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 #ifdef DEC_STAMPS
 	const uint64_t t_start = __builtin_amdgcn_s_memtime();
 #endif
+	for (;;) {
 	if (threadIdx.x == 0)
 		s_ticket = atomicAdd(&a.ctl->ticket, 1u);
 	if (lane < CK)
@@ -1915,6 +1871,10 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 		}
 	}
 	STAMP(6);
+	if (!HUFF)
+		return;
+	__syncthreads(); // the ticket and the tables of this chunk are free again
+	}
 }
 
 // ------------------------------------------------------------------ launchers
@@ -2014,14 +1974,21 @@ void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, int ent, hipStream_t
 	launch_ex_parse_huff(a, fmt, ent, s);
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL(k_chunk_prep_meta, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off, a.in_off,
-			   a.meta, a.nreads, a.chunks, a.gran, a.ctl, a.max_chunks, a.out_n);
+			   a.meta, a.nreads, a.chunks, a.gran, a.ctl, a.max_chunks, a.out_n,
+			   ent == 1 ? (const uint32_t *) a.hread : (const uint32_t *) nullptr);
 	hipLaunchKernelGGL(k_ex_ranks, dim3((a.max_chunks * 8 + 255) / 256), dim3(256), 0, s, a);
 	if (!huff)
 		ktime_begin(1, s);
-	if (huff)
+	if (ent == 1) {
+		// static Huffman: k_huf_emit has written the samples of every read whose lists interleave cleanly;
+		// the chunk table holds the others only (normally none)
+		const uint32_t grid = a.max_chunks < 1024u ? a.max_chunks : 1024u;
+		hipLaunchKernelGGL((k_low_decode_chunked<true>), dim3(grid), dim3(CWG), 0, s, a);
+	} else if (huff) {
 		hipLaunchKernelGGL((k_low_decode_chunked<true>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
-	else
+	} else {
 		hipLaunchKernelGGL((k_low_decode_chunked<false>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
+	}
 	if (!huff)
 		ktime_end(1, s);
 }

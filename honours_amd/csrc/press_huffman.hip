@@ -27,14 +27,21 @@
 //                never synchronises - the rounds before it are only faster); then the codes in front
 //                of every tile and what the read delivers.
 //   k_huf_emit   lane i decodes its subsequence once more from its true start, now with the two-symbol
-//                table, into the wave's LDS staging buffer at its final order (scan of the counts);
-//                the buffer leaves with 16-byte stores.
+//                table, into the wave's LDS staging buffer at its final order (scan of the counts).
+//                The one-byte values do not leave the chip: k_huf_sync also summed the sample deltas they
+//                stand for (per wave and tile, from the same look-up), k_huf_chain made those the sample
+//                value in front of every tile, so the wave turns its staging buffer into samples itself
+//                (zig-zag, running sum, the few exceptions merged in - trans.c:260) and stores int16.
+//                Reads whose lists do not interleave cleanly (a stream that delivers fewer values than
+//                its exceptions assume) keep the two-step way: values to DecodeArgs::low, then
+//                k_low_decode_chunked.
 //
 // Result == huffman.c:1219 bit for bit, including its behaviour at the end of the input
 // (stops when the bytes run out or the symbol count is reached; a code cut off by the end
 // of the input is not delivered).
 
 #include "press_internal.h"
+#include "press_packed.h"
 
 namespace ph {
 
@@ -128,13 +135,18 @@ __device__ __forceinline__ void col_load(uint32_t *col, const uint8_t *src, int3
 	}
 }
 
+// the delta a one-byte value stands for (zig-zag undone)
+__device__ __forceinline__ int32_t unzz8(uint32_t z) { return (int32_t) (z >> 1) ^ -(int32_t) (z & 1u); }
+
 // Count the codes that start in [start, lim) of a column (bit positions relative to the column),
-// stopping at the payload end nb; returns where the next code starts, or HEND.
-// mlut entry: total bits | codes << 4 | bits of the first code << 8 of every whole code that fits in
-// 12 bits; long codes (13 .. 24 bits: one code in 200 of the NA12878 table, one look-up in four has
-// such a lane) through the second-level table of lengths.
-__device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint16_t *mlut, const uint8_t *l2len,
-					     const HuffDev *hd, uint32_t start, uint32_t lim, uint32_t nb, uint32_t &cnt)
+// stopping at the payload end nb, and sum the deltas their symbols stand for (dsum, mod 2^16);
+// returns where the next code starts, or HEND.
+// mlut entry (HuffDev::mlut): total bits | codes << 4 | bits of the first code << 8 | its delta << 12 |
+// sum of the deltas << 20 of every whole code that fits in 12 bits; long codes (13 .. 24 bits: one code
+// in 200 of the NA12878 table, one look-up in four has such a lane) through the second-level table.
+__device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint32_t *mlut, const uint16_t *l2ld,
+					     const HuffDev *hd, uint32_t start, uint32_t lim, uint32_t nb, uint32_t &cnt,
+					     uint32_t &dsum)
 {
 	bool bad = start == HEND;
 	uint32_t p = bad ? 0u : start;
@@ -142,12 +154,15 @@ __device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint16_t
 	if (bad)
 		L = 0;
 	uint32_t c = 0;
-	// length of a long code; 0: the bits are no code
-	auto long_len = [&](uint32_t e, uint32_t wnd) -> uint32_t {
-		if (e == 0xFFFFu)
-			return (trie_code(hd, wnd) >> 24) & 31u; // beyond the second level: the trie in global memory
-		const uint32_t l = l2len[((e & 0x7FFu) << 1) + ((wnd >> HUF_LUT_BITS) & ((1u << ((e >> 11) & 15u)) - 1u))];
-		return l == 0xFFu ? 0u : l;
+	int32_t d = 0;
+	// a long code: bits | delta << 8; 0: the bits are no code
+	auto long_ld = [&](uint32_t e, uint32_t wnd) -> uint32_t {
+		if (e == 0xFFFFFFFFu) { // beyond the second level: the trie in global memory
+			const uint32_t t = trie_code(hd, wnd);
+			return t ? (((t >> 24) & 31u) | (((uint32_t) unzz8(t & 0xFFu) & 0xFFu) << 8)) : 0u;
+		}
+		const uint32_t v = l2ld[(e & 0xFFFu) + ((wnd >> HUF_LUT_BITS) & ((1u << ((e >> 12) & 15u)) - 1u))];
+		return v == 0xFFFFu ? 0u : v;
 	};
 	{
 		int32_t Lm = (int32_t) L - HUF_LUT_BITS; // every code of a look-up starts below L while p <= Lm
@@ -162,16 +177,21 @@ __device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint16_t
 				const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p); // shift = p & 31
 				const uint32_t e = mlut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
 				uint32_t tot = e & 15u, n = (e >> 4) & 15u;
-				if (e & 0x8000u) { // rare (one code in 200): a long code, or none
-					tot = long_len(e, wnd);
+				int32_t dd = (int32_t) (e << 1) >> 21;
+				if ((int32_t) e < 0) { // rare (one code in 200): a long code, or none
+					const uint32_t ld = long_ld(e, wnd);
+					tot = ld & 0xFFu;
 					n = 1;
+					dd = (int32_t) (int8_t) (ld >> 8);
 					if (tot == 0 || p + tot > L) { // no code, or it ends behind the limit:
 						tot = n = 0;           // the careful loop decides
+						dd = 0;
 						Lm = -1;
 					}
 				}
 				p += tot;
 				c += n;
+				d += dd;
 				const uint32_t jn = p >> 5; // a step crosses at most one dword
 				if (jn != j) {
 					w0 = w1;
@@ -190,10 +210,13 @@ __device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint16_t
 		const uint32_t wnd = __builtin_amdgcn_alignbit(col[(j + 1) * 64], col[j * 64], pp);
 		const uint32_t e = mlut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
 		uint32_t tot = e & 15u, n = (e >> 4) & 15u, len1 = (e >> 8) & 15u;
+		int32_t dall = (int32_t) (e << 1) >> 21, d1 = (int32_t) (e << 12) >> 24;
 		bool fail = false;
-		if (any64(act && (e & 0x8000u))) {
-			if (act && (e & 0x8000u)) {
-				tot = len1 = long_len(e, wnd);
+		if (any64(act && (int32_t) e < 0)) {
+			if (act && (int32_t) e < 0) {
+				const uint32_t ld = long_ld(e, wnd);
+				tot = len1 = ld & 0xFFu;
+				dall = d1 = (int32_t) (int8_t) (ld >> 8);
 				fail = tot == 0;
 				n = 1;
 			}
@@ -203,6 +226,7 @@ __device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint16_t
 		if (act && !fail && !cut) {
 			p += fits ? tot : len1;
 			c += fits ? n : 1u;
+			d += fits ? dall : d1;
 		}
 		if (act && (fail || cut)) {
 			bad = true;
@@ -210,6 +234,7 @@ __device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint16_t
 		}
 	}
 	cnt = c;
+	dsum = (uint32_t) d & 0xFFFFu;
 	return bad ? HEND : (p >= nb && p < lim ? HEND : p);
 }
 
@@ -222,26 +247,30 @@ struct TileLds { // what a workgroup keeps per tile besides the tables
 	// one row behind the last column for len_scan's prefetch
 	uint32_t img[HT / 64 + 1][NCOL * 64];
 	uint32_t pad_row[64];
+	uint16_t s_d[HT];
 	uint8_t s_f[HT], s_e[HT], s_c[HT], s_list[HT];
 	uint32_t s_nl[2];
-	uint32_t wtot[HT / 64];
+	uint32_t wtot[HT / 64], wdt[HT / 64];
 };
 
 constexpr uint32_t NO_START = 0xFFu;
 
-// Tile k (all 256 threads of the workgroup call this).  start: NO_START = the first lane runs
-// up through the tile in front like every other lane; else the position (0 .. 30 / R_END) where
-// the tile's first code starts.  Leaves the subsequences' records in a.hrec, the tile's in
-// a.htrec[k] and its `se` also as the return value (same in every thread).
-template <int RU>
-__device__ __forceinline__ uint32_t sync_tile(const DecodeArgs &a, uint32_t k, uint32_t start, TileLds<RU> &T,
-					      const uint16_t *lut, const uint8_t *lut2)
+// Tile k, by the 256 threads of group `grp` of the workgroup; the G groups of a workgroup run their
+// tiles side by side and share the barriers (has = false: a group without a tile only keeps them).
+// start: NO_START = the first lane runs up through the tile in front like every other lane; else the
+// position (0 .. 30 / R_END) where the tile's first code starts.  Leaves the subsequences' records in
+// a.hrec, the tile's in a.htrec[k] and its `se` also as the return value (same in every thread of the group).
+template <int RU, int G>
+__device__ __forceinline__ uint32_t sync_tile(const DecodeArgs &a, uint32_t k, bool has, uint32_t start,
+					      TileLds<RU> *TT, const uint32_t *lut, const uint16_t *lut2)
 {
 	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW;
-	const uint32_t tid = threadIdx.x;
+	const uint32_t grp = G > 1 ? uniform(threadIdx.x >> 8) : 0u;
+	TileLds<RU> &T = TT[grp];
+	const uint32_t tid = threadIdx.x & (HT - 1);
 	const uint32_t lane = tid & 63;
 	const HufTile *dp = a.htiles + k;
-	const uint32_t nbits_t = uniform(dp->nbits);
+	const uint32_t nbits_t = has ? uniform(dp->nbits) : 0u;
 	const uint32_t t = uniform(dp->t_last) & 0x7FFFFFFFu;
 	const uint8_t *src = a.in + dp->src;
 	const int32_t nby = (int32_t) ((nbits_t + 7) >> 3); // (nbits_t < 2^32: below 2^29 bytes)
@@ -261,19 +290,20 @@ __device__ __forceinline__ uint32_t sync_tile(const DecodeArgs &a, uint32_t k, u
 
 	// ---- run-up through the second half of the subsequence in front, then the own one
 	const bool first_known = tid == 0 && exact;
-	uint32_t f, c0, c;
+	uint32_t f, c0, c, dz, dv;
 	{
-		const uint32_t g = len_scan(rcol, lut, lut2, a.huff, first_known ? HEND : (uint32_t) RU, OWN, nbr, c0);
+		const uint32_t g = len_scan(rcol, lut, lut2, a.huff, first_known ? HEND : (uint32_t) RU, OWN, nbr, c0, dz);
 		f = g == HEND ? HEND : g - OWN;
 		if (g == HEND && nb > 0)
 			f = 0; // the guess ran into a bit pattern that is no code: any guess will do
 		if (first_known)
 			f = t == 0 ? 0u : (start == R_END ? HEND : start);
 	}
-	const uint32_t e = len_scan(col, lut, lut2, a.huff, f, OWN, nb, c);
+	const uint32_t e = len_scan(col, lut, lut2, a.huff, f, OWN, nb, c, dv);
 	T.s_f[tid] = (uint8_t) (f == HEND ? R_END : f);
 	T.s_e[tid] = (uint8_t) (e == HEND ? R_END : e - OWN);
 	T.s_c[tid] = (uint8_t) c;
+	T.s_d[tid] = (uint16_t) dv;
 
 	// ---- repair rounds: a lane whose assumed start is not where its left neighbour ended (3 %) is
 	// decoded again from there; thread i is final after at most i rounds, in practice after one or two
@@ -293,7 +323,10 @@ __device__ __forceinline__ uint32_t sync_tile(const DecodeArgs &a, uint32_t k, u
 			T.s_nl[par ^ 1u] = 0;
 		__syncthreads();
 		const uint32_t nl = T.s_nl[par];
-		if (nl == 0)
+		uint32_t nl_any = nl;
+		if (G > 1)
+			nl_any |= TT[grp ^ 1u].s_nl[par];
+		if (nl_any == 0)
 			break;
 		if (tid < 64) {
 			for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
@@ -301,72 +334,90 @@ __device__ __forceinline__ uint32_t sync_tile(const DecodeArgs &a, uint32_t k, u
 				const bool mine = i < nl;
 				const uint32_t u = mine ? T.s_list[i] : 1u;
 				const uint32_t pe = T.s_e[u - 1];
-				uint32_t c2;
+				uint32_t c2, d2;
 				const uint32_t e2 = len_scan(T.img[(u >> 6) + 1] + (u & 63), lut, lut2, a.huff,
 							     (!mine || pe == R_END) ? HEND : pe, OWN,
-							     clamp_nb((int64_t) nbits_t - (int64_t) u * OWN), c2);
+							     clamp_nb((int64_t) nbits_t - (int64_t) u * OWN), c2, d2);
 				if (mine) {
 					T.s_f[u] = (uint8_t) pe;
 					T.s_e[u] = (uint8_t) (e2 == HEND ? R_END : e2 - OWN);
 					T.s_c[u] = (uint8_t) c2;
+					T.s_d[u] = (uint16_t) d2;
 				}
 			}
 		}
 	}
 
-	// ---- the records: per subsequence {start, codes}, per tile {assumed start, end, codes}
+	// ---- the records: per subsequence {start, codes}, per tile {assumed start, end, codes, deltas}
 	const uint32_t cnt = T.s_c[tid];
-	a.hrec[(uint64_t) k * HT + tid] = (uint32_t) T.s_f[tid] | (cnt << 8);
+	if (has)
+		a.hrec[(uint64_t) k * HT + tid] = (uint32_t) T.s_f[tid] | (cnt << 8);
 	const uint32_t inc = wave_scan(cnt);
-	if (lane == 63)
+	const uint32_t dinc = wave_scan((uint32_t) T.s_d[tid]);
+	if (lane == 63) {
 		T.wtot[tid >> 6] = inc;
+		T.wdt[tid >> 6] = dinc & 0xFFFFu;
+	}
 	__syncthreads();
-	uint32_t total = 0;
-#pragma unroll
-	for (int w2 = 0; w2 < HT / 64; w2++)
-		total += T.wtot[w2];
 	const uint32_t se = (uint32_t) T.s_f[0] | ((uint32_t) T.s_e[HT - 1] << 8);
-	if (tid == 0) {
+	if (tid == 0 && has) {
 		HufTRec r;
 		r.se = se;
-		r.count = total;
+		r.count = 0;
+		r.dtot = 0;
+#pragma unroll
+		for (int w2 = 0; w2 < HT / 64; w2++) {
+			r.count += T.wtot[w2];
+			r.dtot += T.wdt[w2];
+			r.wd[w2] = (uint16_t) T.wdt[w2];
+		}
+		r.dtot &= 0xFFFFu;
 		r.base = 0;
-		r.pad = 0;
+		r.dbase = 0;
+		r.fused = 0;
 		a.htrec[k] = r;
 	}
 	__syncthreads(); // the columns and lists are free again
 	return se;
 }
 
-__device__ __forceinline__ void load_len_tables(const HuffDev *hd, uint16_t *mlut, uint8_t *l2len)
+__device__ __forceinline__ void load_len_tables(const HuffDev *hd, uint32_t *mlut, uint16_t *l2ld, uint32_t nthr)
 {
 	const uint4 *s4 = reinterpret_cast<const uint4 *>(hd->mlut);
 	uint4 *d4 = reinterpret_cast<uint4 *>(mlut);
-	for (uint32_t i = threadIdx.x; i < (1u << HUF_LUT_BITS) / 8; i += HT)
+	for (uint32_t i = threadIdx.x; i < (1u << HUF_LUT_BITS) / 4; i += nthr)
 		d4[i] = s4[i];
-	const uint4 *t4 = reinterpret_cast<const uint4 *>(hd->l2len);
-	uint4 *u4 = reinterpret_cast<uint4 *>(l2len);
-	for (uint32_t i = threadIdx.x; i < (uint32_t) HUF_L2_ENTRIES / 16; i += HT)
+	const uint4 *t4 = reinterpret_cast<const uint4 *>(hd->l2ld);
+	uint4 *u4 = reinterpret_cast<uint4 *>(l2ld);
+	for (uint32_t i = threadIdx.x; i < (uint32_t) HUF_L2_ENTRIES / 8; i += nthr)
 		u4[i] = t4[i];
 }
+
+// two tiles side by side share the tables (48 KiB of LDS per workgroup: three on a CU)
+constexpr int SG = 2;
+constexpr int WGS = SG * HT;
 
 // All tiles (LIST = false), or the tiles of a repair round: a.hlist = {tile, true start} pairs, their
 // number in ctl->ticket2.  Persistent workgroups: the tables are loaded once.
 template <int RU, bool LIST>
-__global__ __launch_bounds__(HT, 6) void k_huf_sync(DecodeArgs a)
+__global__ __launch_bounds__(WGS, 6) void k_huf_sync(DecodeArgs a)
 {
-	__shared__ __attribute__((aligned(16))) uint16_t lut[1 << HUF_LUT_BITS];
-	__shared__ __attribute__((aligned(16))) uint8_t lut2[HUF_L2_ENTRIES];
-	__shared__ TileLds<RU> T;
+	__shared__ __attribute__((aligned(16))) uint32_t lut[1 << HUF_LUT_BITS];
+	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
+	__shared__ TileLds<RU> T[SG];
 
 	const uint32_t n = LIST ? min(uniform(a.ctl->ticket2), a.hlist_cap) : min(uniform(a.ctl->nchunks), a.max_htiles);
-	if (blockIdx.x >= n)
+	if (SG * blockIdx.x >= n)
 		return;
-	load_len_tables(a.huff, lut, lut2);
-	for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-		const uint32_t k = LIST ? uniform(a.hlist[2 * i]) : i;
-		const uint32_t st = LIST ? uniform(a.hlist[2 * i + 1]) : NO_START;
-		(void) sync_tile<RU>(a, k, st, T, lut, lut2);
+	const uint32_t grp = uniform(threadIdx.x >> 8);
+	load_len_tables(a.huff, lut, lut2, WGS);
+	for (uint32_t i0 = SG * blockIdx.x; i0 < n; i0 += SG * gridDim.x) {
+		const uint32_t i = i0 + grp;
+		const bool has = i < n; // (an odd count leaves the last group idle)
+		const uint32_t ii = has ? i : i0;
+		const uint32_t k = LIST ? uniform(a.hlist[2 * ii]) : ii;
+		const uint32_t st = LIST ? uniform(a.hlist[2 * ii + 1]) : NO_START;
+		(void) sync_tile<RU, SG>(a, k, has, st, T, lut, lut2);
 	}
 }
 
@@ -395,16 +446,21 @@ __global__ __launch_bounds__(256) void k_huf_tlinks(DecodeArgs a)
 	}
 }
 
-// One workgroup per read: repair what the rounds left (serially - always correct), then the codes in
-// front of every tile and what the read delivers (huffman.c:1243: at most `want` values).
+// the delta a 16-bit zig-zag value stands for, mod 2^16 (trans.c:80)
+__device__ __forceinline__ uint32_t unzz16(uint32_t z) { return ((z >> 1) ^ (0u - (z & 1u))) & 0xFFFFu; }
+
+// One workgroup per read: repair what the rounds left (serially - always correct), then the codes and
+// the sum of the deltas in front of every tile, what the read delivers (huffman.c:1243: at most `want`
+// values), the running sum of the exceptions' deltas (into the upper half of ex_val) and whether
+// k_huf_emit may write the samples itself.
 template <int RU>
-__global__ __launch_bounds__(HT, 6) void k_huf_chain(DecodeArgs a)
+__global__ __launch_bounds__(HT, 4) void k_huf_chain(DecodeArgs a)
 {
-	__shared__ __attribute__((aligned(16))) uint16_t lut[1 << HUF_LUT_BITS];
-	__shared__ __attribute__((aligned(16))) uint8_t lut2[HUF_L2_ENTRIES];
+	__shared__ __attribute__((aligned(16))) uint32_t lut[1 << HUF_LUT_BITS];
+	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
 	__shared__ TileLds<RU> T;
 	__shared__ uint32_t s_first;
-	__shared__ uint32_t s_w[HT / 64];
+	__shared__ uint32_t s_w[HT / 64], s_wd[HT / 64];
 
 	const uint32_t r = blockIdx.x;
 	const uint32_t tid = threadIdx.x;
@@ -428,13 +484,13 @@ __global__ __launch_bounds__(HT, 6) void k_huf_chain(DecodeArgs a)
 		if (u == 0xFFFFFFFFu)
 			break;
 		if (!loaded) {
-			load_len_tables(a.huff, lut, lut2); // (sync_tile's first barrier covers it)
+			load_len_tables(a.huff, lut, lut2, HT); // (sync_tile's first barrier covers it)
 			loaded = true;
 		}
 		// decode from the true start, and on while that moves the end
 		uint32_t pe = (a.htrec[k0 + u - 1].se >> 8) & 0xFFu;
 		for (;;) {
-			const uint32_t se = sync_tile<RU>(a, k0 + u, pe, T, lut, lut2);
+			const uint32_t se = sync_tile<RU, 1>(a, k0 + u, true, pe, &T, lut, lut2);
 			pe = (se >> 8) & 0xFFu;
 			u++;
 			if (u >= nt || (a.htrec[k0 + u].se & 0xFFu) == pe)
@@ -442,13 +498,53 @@ __global__ __launch_bounds__(HT, 6) void k_huf_chain(DecodeArgs a)
 		}
 		t0 = u + 1;
 	}
-	// exclusive prefix of the tiles' counts
+	// exclusive prefix of the tiles' counts and delta sums
 	uint64_t cum = 0;
+	uint32_t dcum = 0;
 	for (uint32_t b = 0; b < nt; b += HT) {
 		const uint32_t u = b + tid;
 		// (tiles decoded again above: read past this CU's L1, which may hold the records as they were)
 		const uint32_t c = u < nt ? __hip_atomic_load(&a.htrec[k0 + u].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+		const uint32_t dt = u < nt ? __hip_atomic_load(&a.htrec[k0 + u].dtot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 		const uint32_t inc = wave_scan(c);
+		const uint32_t dinc = wave_scan(dt);
+		if ((tid & 63) == 63) {
+			s_w[tid >> 6] = inc;
+			s_wd[tid >> 6] = dinc;
+		}
+		__syncthreads();
+		uint32_t before = 0, total = 0, dbefore = 0, dtotal = 0;
+#pragma unroll
+		for (int w2 = 0; w2 < HT / 64; w2++) {
+			const uint32_t x = s_w[w2], y = s_wd[w2];
+			if (w2 < (int) (tid >> 6)) {
+				before += x;
+				dbefore += y;
+			}
+			total += x;
+			dtotal += y;
+		}
+		if (u < nt) {
+			const uint64_t bs = cum + before + inc - c;
+			a.htrec[k0 + u].base = bs > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) bs;
+			a.htrec[k0 + u].dbase = (dcum + dbefore + dinc - dt) & 0xFFFFu;
+		}
+		cum += total;
+		dcum += dtotal;
+		__syncthreads();
+	}
+	const uint32_t want = uniform(a.htiles[k0].want);
+	const uint32_t nlow = cum < want ? (uint32_t) cum : want; // what huffman_decode_memory delivered
+	// running sum of the exceptions' deltas: ex_val[e] = value | (sum of the deltas of exceptions < e) << 16
+	const uint32_t nex = uniform(a.meta[r].nex);
+	const uint64_t o0 = a.htiles[k0].low;
+	uint32_t *val = a.ex_val + o0;
+	uint32_t xcum = 0;
+	for (uint32_t b = 0; b < nex; b += HT) {
+		const uint32_t e = b + tid;
+		const uint32_t z = e < nex ? (val[e] & 0xFFFFu) : 0u;
+		const uint32_t dl = e < nex ? unzz16(z) : 0u;
+		const uint32_t inc = wave_scan(dl);
 		if ((tid & 63) == 63)
 			s_w[tid >> 6] = inc;
 		__syncthreads();
@@ -460,16 +556,20 @@ __global__ __launch_bounds__(HT, 6) void k_huf_chain(DecodeArgs a)
 				before += x;
 			total += x;
 		}
-		if (u < nt) {
-			const uint64_t bs = cum + before + inc - c;
-			a.htrec[k0 + u].base = bs > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) bs;
-		}
-		cum += total;
+		if (e < nex)
+			val[e] = z | (((xcum + before + inc - dl) & 0xFFFFu) << 16);
+		xcum += total;
 		__syncthreads();
 	}
+	// k_huf_emit writes the samples itself if the lists interleave into exactly 1 + nlow + nex samples:
+	// every exception sits among (or right behind) the delivered values
+	const bool fused = nlow >= 1 && (nex == 0 || a.ex_pos[o0 + nex - 1] < nlow + nex);
+	for (uint32_t u = tid; u < nt; u += HT)
+		a.htrec[k0 + u].fused = fused ? 1u : 0u;
 	if (tid == 0) {
-		const uint32_t want = a.htiles[k0].want;
-		a.meta[r].nlow = cum < want ? (uint32_t) cum : want; // what huffman_decode_memory delivered
+		a.meta[r].nlow = nlow;
+		if (fused)
+			a.hread[2 * r + 1] = nt | HUF_FUSED;
 	}
 }
 
@@ -486,9 +586,9 @@ __device__ __forceinline__ void wave_lds_sync()
 
 constexpr uint32_t EMIT_STG = 3328; // staging bytes per wave: 52 per lane (NA12878: 47.4 on average, 64 at most)
 
-// The symbols of the codes that start in [p, L) of the column, at most nmine of them, to wp[0 ..]
-// (LDS staging or the one-byte stream itself).
-// lut entry: sym1 | adv << 8 | sym2 << 16 | len1 << 24 | HUF_TWO; long codes through lut2.
+// The codes that start in [p, L) of the column, at most nmine of them: the DELTA each symbol stands for
+// (zig-zag undone, one signed byte) to wp[0 ..] (LDS staging or the one-byte stream's place).
+// lut entry (HuffDev::lut32): d1 | adv << 8 | d2 << 16 | len1 << 24 | HUF_TWO; long codes through lut2.
 template <typename WP>
 __device__ __forceinline__ void emit_codes(const uint32_t *col, const uint32_t *lut, const uint16_t *lut2,
 					   const HuffDev *hd, uint32_t p, uint32_t L, uint32_t nmine, WP wp)
@@ -496,10 +596,12 @@ __device__ __forceinline__ void emit_codes(const uint32_t *col, const uint32_t *
 	// a long code (13 .. 24 bits) as a one-code entry; 0: the bits are no code (cannot come up in
 	// front of L: k_huf_sync stopped counting there)
 	auto long_entry = [&](uint32_t e, uint32_t wnd) -> uint32_t {
-		if (e == 0xFFFFFFFFu)
-			return trie_code(hd, wnd);
+		if (e == 0xFFFFFFFFu) {
+			const uint32_t t = trie_code(hd, wnd);
+			return t ? ((t & 0xFFFFFF00u) | ((uint32_t) unzz8(t & 0xFFu) & 0xFFu)) : 0u;
+		}
 		const uint32_t e2 = lut2[(e & 0xFFFu) + ((wnd >> HUF_LUT_BITS) & ((1u << ((e >> 12) & 15u)) - 1u))];
-		return e2 == 0xFFFFu ? 0u : ((e2 & 0xFFu) | (e2 & 0x1F00u) | ((e2 & 0x1F00u) << 16));
+		return e2 == 0xFFFFu ? 0u : (((uint32_t) unzz8(e2 & 0xFFu) & 0xFFu) | (e2 & 0x1F00u) | ((e2 & 0x1F00u) << 16));
 	};
 	uint32_t q = 0; // symbols written
 	{
@@ -564,8 +666,221 @@ __device__ __forceinline__ void emit_codes(const uint32_t *col, const uint32_t *
 	}
 }
 
+// ---- samples out of the one-byte values (trans.c:260 undone on the fly)
+//
+// Sample i >= 1 of a read is exception e if pos[e] == i - 1, else one-byte value number (i - 1) -
+// #exceptions in front of it; sample 0 is zd[0] from the header.  In the order of the samples,
+// exception e therefore sits right in front of value number key(e) = pos[e] - e.  A wave that
+// delivers the values [L0, L1) also writes the exceptions with key in [L0, L1) (the one with the
+// read's last value: also those behind it), and the one with value 0: sample 0.
+
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *p, uint32_t n, uint32_t key)
+{
+	uint32_t lo = 0, hi = n;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (p[mid] < key)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	return lo;
+}
+
+// exceptions e with pos[e] - e < key (wave-uniform arguments and result)
+__device__ __forceinline__ uint32_t keys_below(const uint32_t *pos, uint32_t nex, uint32_t key)
+{
+	uint32_t lo = 0, hi = nex;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (uniform(pos[mid]) - mid < key)
+			lo = mid + 1;
+		else
+			hi = mid;
+	}
+	return lo;
+}
+
+// the deltas of the 8 samples at i0 (16 bits each, two per register) with the exceptions
+// [e_first, e_first + e_cnt) merged in; samples outside [Ia, Ib) are left zero.  lowat(l) = delta of one-byte
+// value number l.
+template <typename LOWAT>
+__device__ __forceinline__ void gather8(LOWAT lowat, const uint32_t *pos, const uint32_t *val, uint32_t zd0,
+					uint32_t i0, uint32_t Ia, uint32_t Ib, uint32_t e_first, uint32_t e_cnt,
+					uint32_t v[4])
+{
+	v[0] = v[1] = v[2] = v[3] = 0;
+	const uint32_t lo = i0 > Ia ? i0 : Ia;
+	const uint32_t hi = i0 + 8 < Ib ? i0 + 8 : Ib;
+	if (lo >= hi)
+		return;
+	const uint32_t uf = lo ? lo - 1 : 0;
+	const uint32_t e_end = e_first + e_cnt;
+	uint32_t e = e_first + lower_bound_u32(pos + e_first, e_cnt, uf);
+	uint32_t l = uf - e; // number of the next one-byte value
+	uint32_t nextpos = e < e_end ? pos[e] : 0xFFFFFFFFu;
+#pragma unroll
+	for (int h = 0; h < 8; h++) {
+		const uint32_t i = i0 + h;
+		if (i >= lo && i < hi) {
+			uint32_t dl;
+			if (i == 0) {
+				dl = unzz16(zd0);
+			} else if (i - 1 == nextpos) {
+				dl = unzz16(val[e] & 0xFFFFu);
+				e++;
+				nextpos = e < e_end ? pos[e] : 0xFFFFFFFFu;
+			} else {
+				dl = lowat(l) & 0xFFFFu;
+				l++;
+			}
+			v[h >> 1] |= dl << (16 * (h & 1));
+		}
+	}
+}
+
+struct EmitRead { // what a wave needs of its read to write samples (wave-uniform)
+	const uint32_t *pos, *val;
+	int16_t *out;
+	uint32_t nex, zd0, q, nlow;
+};
+
+// emit_samples' groups of 8 samples start at multiples of 8 samples: 16-byte stores at 16-byte addresses
+// (measured: groups that start at the wave's first sample - stores at any 2-byte address, one ragged round
+// less per wave - make k_huf_emit 4 % slower, at multiples of 2 samples 7 %)
+constexpr uint32_t EMIT_ALIGN = 8;
+
+// 8 signed bytes -> 4 packed pairs of 16-bit values
+__device__ __forceinline__ void expand8s(uint2 dd, uint32_t v[4])
+{
+	typedef short i16x2 __attribute__((ext_vector_type(2)));
+	const i16x2 eight = { 8, 8 };
+	const uint32_t t[4] = { __builtin_amdgcn_perm(0, dd.x, 0x010c000c), __builtin_amdgcn_perm(0, dd.x, 0x030c020c),
+				__builtin_amdgcn_perm(0, dd.y, 0x010c000c), __builtin_amdgcn_perm(0, dd.y, 0x030c020c) };
+#pragma unroll
+	for (int h = 0; h < 4; h++)
+		v[h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, t[h]) >> eight);
+}
+
+// The deltas of the wave's values [L0, L0 + quota) are in src (LDS staging: src[l - L0]; or, GLOBAL, the
+// place of the read's one-byte stream: src[l]): write the samples they and their exceptions make.
+// B0 = sum of the deltas of the values in front of L0 (mod 2^16).
+template <bool GLOBAL>
+__device__ __forceinline__ void emit_samples(const uint8_t *src, const EmitRead &R, uint32_t L0, uint32_t quota,
+					     uint32_t B0, uint32_t lane)
+{
+	const uint32_t L1 = L0 + quota;
+	const uint32_t nex = R.nex;
+	const bool lastw = L1 == R.nlow;
+	// exceptions in front of the wave's first / behind its last sample
+	uint32_t Ea = 0, Eb = 0;
+	if (nex && nex <= 64) {
+		const uint32_t key = lane < nex ? R.pos[lane] - lane : 0xFFFFFFFFu;
+		Ea = (uint32_t) __popcll(__ballot(key < L0));
+		Eb = (uint32_t) __popcll(__ballot(key < L1));
+	} else if (nex) {
+		Ea = keys_below(R.pos, nex, L0);
+		Eb = keys_below(R.pos, nex, L1);
+	}
+	if (lastw)
+		Eb = nex;
+	const uint32_t ecnt = Eb - Ea;
+	const uint32_t Ia = L0 ? L0 + Ea + 1 : 0u;
+	const uint32_t Ib = L1 + Eb + 1;
+	// value of the sample in front of Ia
+	uint32_t base = 0;
+	if (L0) {
+		base = unzz16(R.zd0) + B0;
+		if (Ea) {
+			const uint32_t pv = uniform(R.val[Ea - 1]);
+			base += (pv >> 16) + unzz16(pv & 0xFFFFu);
+		}
+	}
+	// the wave's exceptions, one per lane (more than 64: searched where needed)
+	const uint32_t pe = (ecnt <= 64 && lane < ecnt) ? R.pos[Ea + lane] : 0xFFFFFFFFu;
+	auto ex_below = [&](uint32_t key) -> uint32_t { // exceptions of the wave with pos < key
+		if (ecnt == 0)
+			return 0u;
+		if (ecnt <= 64)
+			return (uint32_t) __popcll(__ballot(pe < key));
+		return uniform(lower_bound_u32(R.pos + Ea, ecnt, key));
+	};
+	const bool shift = uniform(R.q) != 0;
+	const u16x2 qq = { (unsigned short) R.q, (unsigned short) R.q };
+	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+	// 512 samples at a time, 8 per lane, in groups that start at multiples of EMIT_ALIGN samples; the
+	// first and the last round are ragged
+	for (uint32_t g = Ia & ~(EMIT_ALIGN - 1); g < Ib; g += 512) {
+		const uint32_t i0 = g + lane * 8;
+		// exceptions in front of sample g / of sample g + 512
+		const uint32_t e0 = ex_below(g ? g - 1 : 0u), e1 = ex_below(g + 511);
+		const bool plain = !GLOBAL && e0 == e1 && g != 0;
+		const bool ragged = g < Ia || g + 512 > Ib;
+		uint32_t v[4];
+		if (plain) {
+			// sample i = value number i - 1 - (Ea + e0)
+			const bool any = i0 + 8 > Ia && i0 < Ib;
+			const int32_t o = any ? (int32_t) (i0 - 1 - Ea - e0 - L0) : 0; // >= -8 (the staging buffers have room in front)
+			const int32_t j = o >> 2;
+			const uint32_t sh = (uint32_t) (o & 3) * 8u; // (the same in every lane)
+			const uint32_t d0 = s32[j], d1 = s32[j + 1], d2 = s32[j + 2];
+			uint2 dd = make_uint2(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh));
+			if (ragged) {
+				const uint32_t lo = Ia > i0 ? (Ia - i0 < 8 ? Ia - i0 : 8u) : 0u;
+				const uint32_t hi = Ib > i0 ? (Ib - i0 < 8 ? Ib - i0 : 8u) : 0u;
+				uint64_t m = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1ull);
+				m &= lo >= 8 ? 0ull : ~((1ull << (8 * lo)) - 1ull);
+				dd.x &= (uint32_t) m;
+				dd.y &= (uint32_t) (m >> 32);
+			}
+			expand8s(dd, v);
+		} else if (GLOBAL) {
+			gather8([&](uint32_t l) -> uint32_t {
+					return (l >= L0 && l < L1) ? (uint32_t) (int32_t) (int8_t) __hip_atomic_load(src + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+				}, R.pos, R.val, R.zd0, i0, Ia, Ib, Ea, ecnt, v);
+		} else {
+			gather8([&](uint32_t l) -> uint32_t { return (l >= L0 && l < L1) ? (uint32_t) (int32_t) (int8_t) src[l - L0] : 0u; },
+				R.pos, R.val, R.zd0, i0, Ia, Ib, Ea, ecnt, v);
+		}
+		const uint32_t tot = lane_prefix8(v) & 0xFFFFu;
+		const uint32_t inc = wave_incl_scan_dpp(tot);
+		const uint32_t b16 = (base + inc - tot) & 0xFFFFu;
+		const uint32_t b2 = b16 | (b16 << 16);
+#pragma unroll
+		for (int h = 0; h < 4; h++)
+			v[h] = pk_add16(v[h], b2);
+		if (shift) { // ex_zd.c:396 do_rev_qts_inplace
+#pragma unroll
+			for (int h = 0; h < 4; h++)
+				v[h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, v[h]) << qq);
+		}
+		if (!ragged || (i0 >= Ia && i0 + 8 <= Ib)) {
+			const uint4 vv = make_uint4(v[0], v[1], v[2], v[3]);
+			__builtin_memcpy(R.out + i0, &vv, 16);
+		} else {
+#pragma unroll
+			for (uint32_t h = 0; h < 8; h++)
+				if (i0 + h >= Ia && i0 + h < Ib)
+					R.out[i0 + h] = (int16_t) (v[h >> 1] >> (16 * (h & 1)));
+		}
+		base += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+	}
+}
+
+// one-byte values out of their deltas, four at a time (trans.c:74 zig-zag of a byte)
+__device__ __forceinline__ uint32_t zz_bytes(uint32_t d)
+{
+	return ((d << 1) & 0xFEFEFEFEu) ^ (((d >> 7) & 0x01010101u) * 0xFFu);
+}
+
 // two tiles side by side share the tables
 constexpr int WGE = 2 * HT;
+
+struct EmitStg { // the waves' staging buffers; emit_samples reads up to 8 bytes in front of / 12 behind a buffer's content
+	uint8_t pre[16];
+	uint8_t s[WGE / 64][EMIT_STG];
+	uint8_t post[16];
+};
 
 template <int RU>
 __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
@@ -575,7 +890,7 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
 	__shared__ uint32_t img[WGE / 64][NCOL * 64];
 	__shared__ uint32_t pad_row[64];
-	__shared__ __attribute__((aligned(16))) uint8_t stg_all[WGE / 64][EMIT_STG];
+	__shared__ __attribute__((aligned(16))) EmitStg stg_all;
 	__shared__ uint32_t wtot[2][WGE / 64];
 
 	const uint32_t grp = threadIdx.x >> 8;
@@ -598,17 +913,19 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 			u4[i] = t4[i];
 	}
 	uint32_t *col = img[wv] + lane;
-	uint8_t *stg = stg_all[wv];
+	uint8_t *stg = stg_all.s[wv];
 	uint32_t par = 0;
 	// persistent workgroups: the tables are loaded once
 	for (uint32_t k0 = 2 * blockIdx.x; k0 < ntiles; k0 += 2 * gridDim.x, par ^= 1u) {
 		const uint32_t k = k0 + grp;
 		const bool has = k < ntiles; // (an odd tile count leaves the last group idle: it only keeps the barrier)
 		const HufTile *dp = a.htiles + (has ? k : k0);
+		const HufTRec *tr = a.htrec + (has ? k : k0);
 		const uint32_t nbits_t = has ? uniform(dp->nbits) : 0u;
 		const uint32_t want = uniform(dp->want);
 		const uint8_t *src = a.in + dp->src;
-		uint8_t *low = a.low + dp->low;
+		const uint64_t roff = dp->low; // the read's slot: samples in a.sig, one-byte values in a.low, exceptions
+		uint8_t *low = a.low + roff;
 		col_load<NDW>(col, src, (int32_t) tid * (OWN / 8), 0, (int32_t) ((nbits_t + 7) >> 3));
 		const uint32_t nb = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN);
 		const uint32_t rec = has ? a.hrec[(uint64_t) k * HT + tid] : R_END;
@@ -617,11 +934,15 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 		if (lane == 63)
 			wtot[par][wv] = inc;
 		__syncthreads(); // the wave totals (and, the first time, the tables); columns and staging are private
-		uint64_t obase = has ? uniform(a.htrec[k].base) : 0u; // codes of the read in front of this wave
+		uint64_t obase = has ? uniform(tr->base) : 0u; // codes of the read in front of this wave
+		uint32_t B0 = uniform(tr->dbase);              // ... and the sum of their deltas
 #pragma unroll
 		for (int w2 = 0; w2 < HT / 64; w2++)
-			if (w2 < (int) (tid >> 6))
+			if (w2 < (int) (tid >> 6)) {
 				obase += uniform(wtot[par][grp * (HT / 64) + w2]);
+				B0 += uniform((uint32_t) tr->wd[w2]);
+			}
+		const bool fused = has && uniform(tr->fused) != 0;
 		const uint32_t wsum = uniform((uint32_t) __shfl((int) inc, 63, 64));
 		// the wave delivers values [obase, obase + wsum) of the read, cut at `want`
 		const uint32_t quota = obase >= want ? 0u : (wsum < want - (uint32_t) obase ? wsum : want - (uint32_t) obase);
@@ -633,25 +954,52 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 		uint32_t L = (uint32_t) OWN < nb ? (uint32_t) OWN : nb;
 		if (f == R_END || nmine == 0)
 			L = 0;
-		// symbols go to the wave's staging buffer in their final order and leave it with 16-byte stores;
-		// a wave that holds more codes than the buffer takes (cannot happen with 5.4-bit codes on
-		// average) stores them byte by byte instead
+		EmitRead R = {};
+		if (fused) {
+			const ReadMeta *m = a.meta + uniform(dp->read);
+			R.pos = a.ex_pos + roff;
+			R.val = a.ex_val + roff;
+			R.out = a.sig + roff;
+			R.nex = uniform(m->nex);
+			R.zd0 = uniform(m->zd0);
+			R.q = uniform(m->q);
+			R.nlow = uniform(m->nlow);
+		}
+		// symbols go to the wave's staging buffer in their final order; a wave that holds more codes than
+		// the buffer takes (cannot happen with 5.4-bit codes on average) stores them byte by byte instead
 		if (wsum <= EMIT_STG) {
 			emit_codes(col, lut, lut2, a.huff, p0, L, nmine, stg + ex);
 			wave_lds_sync();
-			for (uint32_t o = lane * 16; o < quota; o += 64 * 16) {
-				const uint4 v = *reinterpret_cast<const uint4 *>(stg + o);
-				if (o + 16 <= quota) {
-					__builtin_memcpy(dst + o, &v, 16); // any byte address
-				} else {
-					const uint32_t vv[4] = { v.x, v.y, v.z, v.w };
-					for (uint32_t b = 0; o + b < quota; b++)
-						dst[o + b] = (uint8_t) (vv[b >> 2] >> (8 * (b & 3)));
+			if (fused) {
+				if (quota)
+					emit_samples<false>(stg, R, (uint32_t) obase, quota, B0, lane);
+			} else {
+				// the one-byte stream, for k_low_decode_chunked: 16-byte stores
+				for (uint32_t o = lane * 16; o < quota; o += 64 * 16) {
+					uint4 v = *reinterpret_cast<const uint4 *>(stg + o);
+					v = make_uint4(zz_bytes(v.x), zz_bytes(v.y), zz_bytes(v.z), zz_bytes(v.w));
+					if (o + 16 <= quota) {
+						__builtin_memcpy(dst + o, &v, 16); // any byte address
+					} else {
+						const uint32_t vv[4] = { v.x, v.y, v.z, v.w };
+						for (uint32_t b = 0; o + b < quota; b++)
+							dst[o + b] = (uint8_t) (vv[b >> 2] >> (8 * (b & 3)));
+					}
 				}
 			}
 			wave_lds_sync(); // staging is free again
 		} else {
 			emit_codes(col, lut, lut2, a.huff, p0, L, nmine, dst + ex);
+			if (fused && quota) {
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the wave reads back what its lanes wrote
+				__builtin_amdgcn_wave_barrier();
+				emit_samples<true>(low, R, (uint32_t) obase, quota, B0, lane);
+			} else if (!fused) {
+				for (uint32_t b = 0; b < nmine; b++) { // deltas -> one-byte values, in place
+					const uint32_t dl = dst[ex + b];
+					dst[ex + b] = (uint8_t) ((dl << 1) ^ (0u - (dl >> 7)));
+				}
+			}
 		}
 	}
 }
@@ -718,15 +1066,15 @@ __global__ __launch_bounds__(256) void k_huff_tiles(DecodeArgs a)
 template <int RU>
 static void run_huff_decode(const DecodeArgs &a, hipStream_t s)
 {
-	// persistent workgroups: what is resident (6 per CU; emit: 2 of twice the size)
+	// persistent workgroups: what is resident (sync: 3 per CU, emit: 2, both of two tiles)
 	const uint32_t nt = a.max_htiles ? a.max_htiles : 1;
-	const uint32_t grid = nt < 6u * 256u ? nt : 6u * 256u;
+	const uint32_t grid = (nt + 1) / 2 < 3u * 256u ? (nt + 1) / 2 : 3u * 256u;
 	const uint32_t ge = (nt + 1) / 2 < 2u * 256u ? (nt + 1) / 2 : 2u * 256u;
-	hipLaunchKernelGGL((k_huf_sync<RU, false>), dim3(grid), dim3(HT), 0, s, a);
+	hipLaunchKernelGGL((k_huf_sync<RU, false>), dim3(grid), dim3(WGS), 0, s, a);
 	for (int round = 0; round < HUF_FIX_ROUNDS; round++) {
 		(void) hipMemsetAsync(&a.ctl->ticket2, 0, 4, s);
 		hipLaunchKernelGGL(k_huf_tlinks, dim3((nt + 255) / 256), dim3(256), 0, s, a);
-		hipLaunchKernelGGL((k_huf_sync<RU, true>), dim3(grid), dim3(HT), 0, s, a);
+		hipLaunchKernelGGL((k_huf_sync<RU, true>), dim3(grid), dim3(WGS), 0, s, a);
 	}
 	hipLaunchKernelGGL((k_huf_chain<RU>), dim3(a.nreads), dim3(HT), 0, s, a);
 	hipLaunchKernelGGL((k_huf_emit<RU>), dim3(ge), dim3(WGE), 0, s, a);

@@ -44,31 +44,43 @@ struct HuffDev {
 	uint16_t l2off[256];
 	uint8_t l2bits[256];
 	// two-symbol first level for the parallel decoder:
-	//   sym1 | adv << 8 | sym2 << 16 | len1 << 24 | HUF_TWO,  adv = len1 + len2 with HUF_TWO (two whole
-	//   codes fit in HUF_LUT_BITS bits), else adv = len1 and sym2 = 0
-	// (the two symbols sit in the low bytes of the two register halves: ds_write_b8 / _d16_hi store
+	//   d1 | adv << 8 | d2 << 16 | len1 << 24 | HUF_TWO,  adv = len1 + len2 with HUF_TWO (two whole
+	//   codes fit in HUF_LUT_BITS bits), else adv = len1 and d2 = 0;  d = the delta the symbol stands for
+	//   (zig-zag undone, a signed byte)
+	// (the two deltas sit in the low bytes of the two register halves: ds_write_b8 / _d16_hi store
 	// them without a shift); a long code's prefix: HUF_LONG | l2bits << 12 | l2off of its
 	// second-level table; 0xFFFFFFFF: walk the trie
 	alignas(16) uint32_t lut32[1 << HUF_LUT_BITS];
-	// length-only first level for k_huf_sync: every whole code that fits in HUF_LUT_BITS bits at once:
-	// total bits | codes << 4 | bits of the first code << 8; a long code's prefix:
-	// 0x8000 | l2bits << 11 | l2off / 2 (its length is l2len[l2off + the next l2bits stream bits],
-	// 0xFF: no such code); 0xFFFF: walk the trie
-	alignas(16) uint16_t mlut[1 << HUF_LUT_BITS];
-	alignas(16) uint8_t l2len[HUF_L2_ENTRIES];
+	// first level of k_huf_sync (lengths and sample deltas, no symbols): every whole code that fits in
+	// HUF_LUT_BITS bits at once (at most HUF_M_MAXN of them):
+	//   total bits | codes << 4 | bits of the first code << 8 | d1 << 12 | dsum << 20
+	//   d1 = delta the first code's symbol stands for (8 bits, signed: zig-zag undone), dsum = sum of the
+	//   deltas of all codes of the entry (11 bits, signed);
+	// a long code's prefix: HUF_MLONG | l2off | l2bits << 12 (length and delta of the code in
+	// l2ld[l2off + the next l2bits stream bits]); 0xFFFFFFFF: walk the trie
+	alignas(16) uint32_t mlut[1 << HUF_LUT_BITS];
+	alignas(16) uint16_t l2ld[HUF_L2_ENTRIES]; // bits of the code | delta << 8 (signed), 0xFFFF: no such code
 };
+constexpr uint32_t HUF_MLONG = 1u << 31; // (the sign bit: one compare)
+constexpr uint32_t HUF_M_MAXN = 8; // 8 deltas of -128 .. 127 fit the 11-bit sum
 constexpr uint32_t HUF_LONG = 1u << 30;
 constexpr uint32_t HUF_TWO = 1u << 29;
 
 // parallel Huffman decode (press_huffman.hip): tiles of HUF_HT subsequences, one workgroup each
 constexpr int HUF_HT = 256;        // threads per workgroup = subsequences per tile
 constexpr int HUF_FIX_ROUNDS = 2;  // parallel tile repair rounds before the serial pass of k_huf_chain
-struct HufTRec {             // what k_huf_sync leaves per tile (16 bytes)
+struct HufTRec {             // what k_huf_sync leaves per tile (32 bytes)
 	uint32_t se;         // start it assumed | where the next tile's first code starts << 8 (0 .. 30, 31 = none)
 	uint32_t count;      // codes that start in the tile
 	uint32_t base;       // codes of the read in front of the tile (k_huf_chain)
-	uint32_t pad;
+	uint32_t dbase;      // sum of their deltas, mod 2^16 (k_huf_chain)
+	uint16_t wd[4];      // sum of the deltas of the codes of each wave's 64 subsequences, mod 2^16
+	uint32_t dtot;       // ... of the tile
+	uint32_t fused;      // k_huf_chain: 1 = k_huf_emit writes the read's samples itself, 0 = its one-byte
+	                     // values go to DecodeArgs::low and k_low_decode_chunked merges them
 };
+static_assert(sizeof(HufTRec) == 32, "HufTRec");
+constexpr uint32_t HUF_FUSED = 0x80000000u; // in DecodeArgs::hread[2r + 1]: the read needs no k_low_decode_chunked
 
 // ---- chunked (v2) svb kernels: a read is cut into chunks of CHUNK samples, one workgroup
 // per chunk; chunks of a read are chained by a decoupled look-back over 8-byte granules.

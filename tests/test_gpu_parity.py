@@ -481,6 +481,47 @@ def test_huffman_truncated_payload(oracle):
             assert bg.size == bo.size and np.array_equal(bg, bo), (cut, bg.size, bo.size)
 
 
+def test_huffman_sample_writer_paths(oracle):
+    """k_huf_emit writes the samples itself (press_huffman.hip emit_samples): reads built to reach its
+    corners - exceptions in front of the first and behind the last one-byte value, runs of more than 64
+    exceptions inside one wave's range, reads with more than 64 exceptions, a single one-byte value among
+    exceptions, and 4-bit codes throughout (a wave then holds more codes than its staging buffer and
+    goes through the one-byte stream's place in memory).  Byte parity and lossless both ways."""
+    m = "shuffman_vbe21_zd"
+    rng = np.random.default_rng(11)
+    reads = []
+    base = np.cumsum(rng.integers(-12, 13, size=90000)).astype(np.int64) + 500
+    a = base.copy()
+    a[1:4] += 3000          # the first samples behind sample 0 are exceptions
+    a[-3:] -= 3000          # ... and the last ones
+    reads.append(a)
+    b = base.copy()
+    b[40000:40300:1] += (np.arange(300) % 2) * 900   # 300 exceptions in a row: more than 64 in one wave
+    reads.append(b)
+    c = base.copy()
+    jump = rng.random(c.size) < 0.02                 # ~1800 exceptions all over
+    c[jump] += 700
+    reads.append(c)
+    d = np.array([100, 900, 100, 901, 100, 100, 900, 101], dtype=np.int64)  # little besides exceptions
+    reads.append(d)
+    for dl in (-2, -1, 1, 2, 0):                     # one of these has a 4-bit code in the NA12878 table
+        reads.append(500 + dl * np.arange(70000, dtype=np.int64) % 1500)
+    reads.append(np.full(70000, 777, dtype=np.int64))
+    for r in reads:
+        sig = r.astype(np.int16)
+        if shuff_ok(m, sig):
+            check_read(oracle, m, sig)
+    # and all of them in one batch call
+    sigs = [r.astype(np.int16) for r in reads if shuff_ok(m, r.astype(np.int16))]
+    streams = press.press_batch_host(m, sigs)
+    for sgl, st in zip(sigs, streams):
+        ret, want = oracle.press(m, sgl)
+        assert ret == 0 and st == want
+    backs = press.depress_batch_host(m, streams, [len(x) for x in sigs])
+    for sgl, bk in zip(sigs, backs):
+        assert bk is not None and np.array_equal(bk, sgl)
+
+
 def test_longest_read_in_a_mixed_batch(oracle):
     """a read of NA12878's maximum length (5.7 M samples: 175 chunks, ~420 Huffman tiles - deep
     look-back chains) next to tiny reads in ONE batch call, byte parity with the oracle for the
