@@ -1125,7 +1125,9 @@ __global__ __launch_bounds__(256) void k_ex_redo_flag(BatchArgs a)
 template <bool REDO, bool HUFF = false>
 __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 {
-	__shared__ uint8_t s_len[HUFF ? 256 : 4];
+	// code length of every one-byte value, 1 << 16 for a value without a code; [256] = 0: what a sample that
+	// is no one-byte value (exception, sample 0, outside the read) looks up
+	__shared__ uint32_t s_len[HUFF ? 257 : 1];
 	if (REDO && uni(a.ctl->pad0[0]) == 0)
 		return; // no read of this batch has q > 0 (the common case)
 	const uint32_t t = blockIdx.x;
@@ -1134,7 +1136,10 @@ __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 	const int lane = threadIdx.x & 63;
 	const int w = (int) uni(threadIdx.x >> 6);
 	if (HUFF) {
-		s_len[threadIdx.x] = (uint8_t) (a.huff->enc[threadIdx.x] >> 24);
+		const uint32_t l = a.huff->enc[threadIdx.x] >> 24;
+		s_len[threadIdx.x] = l ? l : 0x10000u;
+		if (threadIdx.x == 0)
+			s_len[256] = 0;
 		__syncthreads();
 	}
 	ChunkDesc *dp = a.chunks + t;
@@ -1191,12 +1196,8 @@ __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 				const uint32_t lowm = low_mask(z, i0, n);
 				const uint32_t zz[4] = { z.x, z.y, z.z, z.w };
 #pragma unroll
-				for (int h = 0; h < 8; h++) {
-					const uint32_t l = s_len[(zz[h >> 1] >> (16 * (h & 1))) & 0xFFu];
-					lbits += ((lowm >> h) & 1u) ? l : 0u;
-					if (((lowm >> h) & 1u) && l == 0)
-						nocode = 0x80000000u; // a value the table has no code for: the read fails (k_ex_section)
-				}
+				for (int h = 0; h < 8; h++) // (a lane sums 128 values of at most 24 bits: below 1 << 16)
+					lbits += s_len[((lowm >> h) & 1u) ? ((zz[h >> 1] >> (16 * (h & 1))) & 0xFFu) : 256u];
 			}
 		}
 #pragma unroll
@@ -1204,6 +1205,9 @@ __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 			raw[k] = nxt[k];
 	}
 	if (HUFF) {
+		if (lbits >> 16)
+			nocode = 0x80000000u; // a value the table has no code for: the read fails (k_ex_section)
+		lbits &= 0xFFFFu;
 		const uint32_t inc = wave_incl_scan_dpp(lbits);
 		if (lane == 63)
 			a.cbits[t].q[w] = inc;
@@ -1414,10 +1418,12 @@ __device__ __forceinline__ uint32_t huff_tail_bits(const int16_t *in, uint32_t e
 
 __global__ __launch_bounds__(CWG) void k_huff_encode_chunked(BatchArgs a)
 {
-	__shared__ uint32_t enc[256];
+	__shared__ uint32_t enc[257]; // [256] = 0: what a sample without a code (exception, outside the read) looks up
 	__shared__ uint32_t stg_all[4][HSTG];
 
 	enc[threadIdx.x] = a.huff->enc[threadIdx.x];
+	if (threadIdx.x == 0)
+		enc[256] = 0;
 	for (uint32_t i = threadIdx.x; i < 4u * HSTG; i += CWG)
 		(&stg_all[0][0])[i] = 0;
 	__syncthreads(); // the only barrier
@@ -1491,21 +1497,42 @@ __global__ __launch_bounds__(CWG) void k_huff_encode_chunked(BatchArgs a)
 		uint32_t lb = 0;
 #pragma unroll
 		for (int h = 0; h < 8; h++) {
-			e[h] = enc[(zz[h >> 1] >> (16 * (h & 1))) & 0xFFu];
-			lb += ((lowm >> h) & 1u) ? (e[h] >> 24) : 0u;
+			e[h] = enc[((lowm >> h) & 1u) ? ((zz[h >> 1] >> (16 * (h & 1))) & 0xFFu) : 256u];
+			lb += e[h] >> 24;
 		}
 		const uint32_t inc = wave_incl_scan_dpp(lb);
 		const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
 		uint32_t pos = fill + inc - lb;
+		if (lb <= 64) {
+			// the lane's codes side by side in two registers (8 codes of the NA12878 table: 43 bits on
+			// average, more than 64 in one lane of 700), then at most three LDS atomics
+			uint64_t acc = 0;
+			uint32_t o = 0;
 #pragma unroll
-		for (int h = 0; h < 8; h++) {
-			if ((lowm >> h) & 1u) {
-				const uint64_t wv = (uint64_t) (e[h] & 0xFFFFFFu) << (pos & 31u);
-				if ((uint32_t) wv)
-					atomicOr(&stg[pos >> 5], (uint32_t) wv);
-				if ((uint32_t) (wv >> 32))
-					atomicOr(&stg[(pos >> 5) + 1], (uint32_t) (wv >> 32));
-				pos += e[h] >> 24;
+			for (int h = 0; h < 8; h++) {
+				acc |= (uint64_t) (e[h] & 0xFFFFFFu) << o;
+				o += e[h] >> 24;
+			}
+			const uint32_t sh = pos & 31u;
+			const uint64_t lo2 = acc << sh;
+			const uint32_t w2 = sh ? (uint32_t) (acc >> 32) >> (32u - sh) : 0u;
+			if ((uint32_t) lo2)
+				atomicOr(&stg[pos >> 5], (uint32_t) lo2);
+			if ((uint32_t) (lo2 >> 32))
+				atomicOr(&stg[(pos >> 5) + 1], (uint32_t) (lo2 >> 32));
+			if (w2)
+				atomicOr(&stg[(pos >> 5) + 2], w2);
+		} else {
+#pragma unroll
+			for (int h = 0; h < 8; h++) {
+				if (e[h]) {
+					const uint64_t wv = (uint64_t) (e[h] & 0xFFFFFFu) << (pos & 31u);
+					if ((uint32_t) wv)
+						atomicOr(&stg[pos >> 5], (uint32_t) wv);
+					if ((uint32_t) (wv >> 32))
+						atomicOr(&stg[(pos >> 5) + 1], (uint32_t) (wv >> 32));
+					pos += e[h] >> 24;
+				}
 			}
 		}
 		wave_lds_sync();
