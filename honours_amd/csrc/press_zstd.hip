@@ -1201,9 +1201,11 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 			active = false;
 		}
 	}
-	// The stream is read backwards from its end mark: bp = stream bits not yet used.  No bit
-	// window in registers (its 64-bit shifts run at a quarter of the rate and made this kernel
-	// VALU bound): the 11 bits below bp are cut out of the staged dwords at every step.
+	// The stream is read backwards from its end mark: bp = stream bits not yet used.  No 64-bit bit
+	// window (its shifts run at a quarter of the rate and made this kernel VALU bound): the 11 bits below
+	// bp are cut out of two staged dwords that stay in registers.
+	// (Measured and dropped, round 2: a two-symbol table over 10 index bits, as much LDS as this one - 1.55
+	// symbols per step, but with its longer step 2.05 .. 2.3 ms against 1.83 ms.)
 	int32_t bp = 0;
 	bool overrun = false;
 	if (active)
@@ -1257,17 +1259,25 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 		}
 		uint32_t acc = 0;
 		const int32_t c0 = 32 - 11 - 8 * base; // slot bit of stream bit b: b + 32 - 8 base
+		// the two dwords around slot bit bp + c0 stay in registers; the dword below them is fetched while
+		// the table look-up is in flight (a step moves down by at most 11 bits: at most one dword)
+		uint32_t w0 = (uint32_t) (bp + c0) >> 5;
+		uint32_t lo = myin[w0], hi = myin[w0 + 1];
 		for (uint32_t i = 0; i < cnt; i++) {
-			const uint32_t sb = (uint32_t) (bp + c0);
-			const uint32_t w0 = sb >> 5;
-			const uint32_t lo = myin[w0], hi = myin[w0 + 1];
-			const uint32_t v11 = __builtin_amdgcn_alignbit(hi, lo, sb & 31u) & 0x7FFu;
+			const uint32_t below = myin[w0 ? w0 - 1 : 0];
+			const uint32_t v11 = __builtin_amdgcn_alignbit(hi, lo, (uint32_t) (bp + c0)) & 0x7FFu; // shift = low 5 bits
 			const uint32_t e = dt[v11 >> tsh];
 			bp -= (int32_t) (e >> 8);
 			if (bp < 0) { // more code bits than the stream has
 				overrun = true;
 				bp = 0;
 			}
+			const uint32_t wn = (uint32_t) (bp + c0) >> 5;
+			if (wn != w0) {
+				hi = lo;
+				lo = below;
+			}
+			w0 = wn;
 			acc |= (e & 0xFFu) << (8 * (i & 3));
 			if ((i & 3) == 3) {
 				myout[i >> 2] = acc;

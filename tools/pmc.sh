@@ -11,7 +11,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(float)); disp=collec
 for r in csv.DictReader(open(f)):
     k=r["Kernel_Name"]
     if "ph::" not in k: continue
-    k=k.split("(")[0].replace("void ph::","")
+    k=k.replace("(anonymous namespace)::","").split("(")[0].replace("void ph::","").replace("ph::","")
     agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
 for k,v in agg.items():
     n=len(disp[k])
