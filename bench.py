@@ -54,6 +54,7 @@ WORKLOADS = {
     "zstd_hasgam_vbsse21_zdq": "zstd(ex-zd), zstd frames made and read on the device",
     "rc_vbe21_zd": "exception split + order-0 adaptive range coder (rc_vbe21_zd; serial per read by format)",
     "rcc_vbe21_zd": "exception split + order-1 adaptive range coder (rcc_vbe21_zd; serial per read by format)",
+    "rccm_vbbe21_zd": "exception split + order 1-0 context-mixing range coder (rccm_vbbe21_zd; serial per read by format)",
 }
 
 # (press kernel, depress kernel): the kernels press_hip_kernel_timing() brackets with HIP events
@@ -63,6 +64,7 @@ KERNELS = {
     "slow5_svb_zd": ("k_svb_encode_chunked<true,true,true>", "k_svb_decode_chunked<true,true,true>"),
     "rc_vbe21_zd": ("k_rcs_encode", "k_rcs_decode"),
     "rcc_vbe21_zd": ("k_rcc_encode", "k_rcc_decode"),
+    "rccm_vbbe21_zd": ("k_rcm_encode", "k_rcm_decode"),
     "zstd_svb_zd": ("k_zs_encode", "k_zs_hdecode"),
     "zstd_svb12_zd": ("k_zs_encode", "k_zs_hdecode"),
     "zstd_hasgam_vbsse21_zdq": ("k_zs_encode", "k_zs_hdecode"),
@@ -72,7 +74,7 @@ KERNELS = {
 # "hbm" = streams at the memory system's rate; "valu" = instruction issue (HBM time of its bytes is a fraction)
 LIMITER = {"shuffman_vbe21_zd": "valu", "zstd_svb_zd": "valu", "zstd_svb12_zd": "valu",
            "zstd_hasgam_vbsse21_zdq": "valu", "rc_vbe21_zd": "valu (serial per read)",
-           "rcc_vbe21_zd": "valu (serial per read)"}
+           "rcc_vbe21_zd": "valu (serial per read)", "rccm_vbbe21_zd": "valu (serial per read)"}
 
 
 def kernel_own_bytes(m, which, raw, comp, nsamp):

@@ -182,7 +182,7 @@ bool is_zstd(int m)
 {
 	return m == PRESS_HIP_ZSTD_SVB_ZD || m == PRESS_HIP_ZSTD_SVB12_ZD || m == PRESS_HIP_ZSTD_HASGAM_ZDQ;
 }
-bool is_rc(int m) { return m == PRESS_HIP_RC_VBE21_ZD || m == PRESS_HIP_RCC_VBE21_ZD; }
+bool is_rc(int m) { return m == PRESS_HIP_RC_VBE21_ZD || m == PRESS_HIP_RCC_VBE21_ZD || m == PRESS_HIP_RCCM_VBBE21_ZD; }
 bool is_zs(int m) { return m == PRESS_HIP_ZSTD_SVB_ZD || m == PRESS_HIP_ZSTD_SVB12_ZD || m == PRESS_HIP_ZSTD_HASGAM_ZDQ; } // zstd frames made on the device (batch API)
 int zs_inner(int m) { return m == PRESS_HIP_ZSTD_SVB_ZD ? PRESS_HIP_SVB_ZD : m == PRESS_HIP_ZSTD_SVB12_ZD ? PRESS_HIP_SVB12_ZD : PRESS_HIP_HASGAM_ZDQ; }
 uint32_t zs_kdiv(int m) { return m == PRESS_HIP_ZSTD_SVB_ZD ? 4 : m == PRESS_HIP_ZSTD_SVB12_ZD ? 8 : 0; }
@@ -192,13 +192,13 @@ uint64_t zs_tmp_bytes(int m, uint64_t total_samples, uint32_t nreads)
 	return (zs_kdiv(m) ? total_samples * 9 / 4 : total_samples * 9) + ((uint64_t) nreads + 1) * 128 + 64;
 }
 bool is_ex(int m) { return (m >= PRESS_HIP_VBE21_ZD && m <= PRESS_HIP_HASGAM_ZDQ) || is_rc(m); }
-int entropy_of(int m) { return is_shuff(m) ? 1 : m == PRESS_HIP_RC_VBE21_ZD ? 2 : m == PRESS_HIP_RCC_VBE21_ZD ? 3 : 0; }
+int entropy_of(int m) { return is_shuff(m) ? 1 : m == PRESS_HIP_RC_VBE21_ZD ? 2 : m == PRESS_HIP_RCC_VBE21_ZD ? 3 : m == PRESS_HIP_RCCM_VBBE21_ZD ? 4 : 0; }
 
 int exfmt_of(int m)
 {
 	switch (m) {
 	case PRESS_HIP_VBE21_ZD: case PRESS_HIP_SHUFF_VBE21_ZD: case PRESS_HIP_RC_VBE21_ZD: case PRESS_HIP_RCC_VBE21_ZD: return EXF_VBE21;
-	case PRESS_HIP_VBBE21_ZD: case PRESS_HIP_SHUFF_VBBE21_ZD:   return EXF_VBBE21;
+	case PRESS_HIP_VBBE21_ZD: case PRESS_HIP_SHUFF_VBBE21_ZD: case PRESS_HIP_RCCM_VBBE21_ZD: return EXF_VBBE21;
 	case PRESS_HIP_VBSBE21_ZD: case PRESS_HIP_SHUFF_VBSBE21_ZD: return EXF_VBSBE21;
 	case PRESS_HIP_VBSSE21_ZD: case PRESS_HIP_SHUFF_VBSSE21_ZD: return EXF_VBSSE21;
 	default:                                                    return EXF_EXZD;
@@ -1741,6 +1741,16 @@ void rcc_vbe21_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64
 void rcc_vbe21_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout)
 {
 	void_depress(PRESS_HIP_RCC_VBE21_ZD, in, nin, out, nout);
+}
+// rccm_vbbe21_zd (press.c:6901-7000): vbbe21 + the order 1-0 context-mixing coder
+uint64_t rccm_vbbe21_zd_bound_16(uint32_t nin) { return press_hip_bound(PRESS_HIP_RCCM_VBBE21_ZD, nin); }
+void rccm_vbbe21_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout)
+{
+	void_press(PRESS_HIP_RCCM_VBBE21_ZD, in, nin, out, nout);
+}
+void rccm_vbbe21_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout)
+{
+	void_depress(PRESS_HIP_RCCM_VBBE21_ZD, in, nin, out, nout);
 }
 
 #define SHUFF_FAMILY(name, id)                                                                           \

@@ -1979,8 +1979,10 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, int ent, hipStream_t 
 		ktime_begin(0, s);
 		if (ent == 2)
 			launch_rcs_encode(a, s);
-		else
+		else if (ent == 3)
 			launch_rcc_encode(a, s);
+		else
+			launch_rcm_encode(a, s);
 		ktime_end(0, s);
 		return;
 	}

@@ -263,7 +263,7 @@ void ktime_mute(bool m); // a composite launcher times its own kernel instead of
 // launchers.  All asynchronous on `s`.
 void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStream_t s, bool slow5 = false); // chunks + look-back
 void launch_svb_decode_chunked(const DecodeArgs &a, bool key2bit, bool zd, hipStream_t s, bool slow5 = false);
-void launch_ex_encode_chunked(const BatchArgs &a, int fmt, int ent, hipStream_t s); // ent: 0 plain, 1 Huffman, 2 / 3 range coder of order 0 / 1
+void launch_ex_encode_chunked(const BatchArgs &a, int fmt, int ent, hipStream_t s); // ent: 0 plain, 1 Huffman, 2 / 3 / 4 range coder of order 0 / 1 / 1-0 mixing
 void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, int ent, hipStream_t s);
 void launch_ex_parse_huff(const DecodeArgs &a, int fmt, int ent, hipStream_t s); // press_sections.hip
 void launch_huff_decode(const DecodeArgs &a, uint32_t minlen, hipStream_t s);      // press_huffman.hip
@@ -272,5 +272,7 @@ void launch_rcs_encode(const BatchArgs &a, hipStream_t s);  // press_rc.hip
 void launch_rcs_decode(const DecodeArgs &a, hipStream_t s);
 void launch_rcc_encode(const BatchArgs &a, hipStream_t s);  // order 1 (rcc_vbe21_zd)
 void launch_rcc_decode(const DecodeArgs &a, hipStream_t s);
+void launch_rcm_encode(const BatchArgs &a, hipStream_t s);  // order 1-0 context mixing (rccm_vbbe21_zd)
+void launch_rcm_decode(const DecodeArgs &a, hipStream_t s);
 
 } // namespace ph

@@ -1,6 +1,6 @@
-// press_rc.hip - the order-0 adaptive binary range coder of rc_vbe21_zd:
-// TurboRC's rcsenc / rcsdec as the reference calls them (press.c:5456, 5489) on the one-byte
-// values of the vbe21 exception split.
+// press_rc.hip - the adaptive binary range coders of rc_vbe21_zd, rcc_vbe21_zd and
+// rccm_vbbe21_zd (8f-4).  First the order-0 coder: TurboRC's rcsenc / rcsdec as the reference calls them
+// (press.c:5456, 5489) on the one-byte values of the vbe21 exception split.
 //
 // The format leaves a GPU nothing to parallelise inside a read: the 255 adaptive probabilities
 // and the 64-bit interval run through the whole stream, bit by bit (~1 M dependent steps for a
@@ -463,6 +463,279 @@ __global__ __launch_bounds__(RCC_WG) void k_rcc_decode(DecodeArgs a)
 		}
 		__syncthreads();
 	}
+}
+
+// ------------------------------------------------------------------ order 1-0 context mixing: rccm_vbbe21_zd
+//
+// rcmsenc / rcmsdec (Turbo-Range-Coder rccm_.c:79-121 as rccm_s.c:46-48 instantiates it: 16-bit
+// probabilities, simple predictor with the rate as parameter; press.c:6946, 6987).  The same interval
+// arithmetic, renormalised in front of EVERY bit; the probability of a bit is a mix (mbc.h:185-193):
+//   p0 = order-0 predictor of the bit's node, p1 = the node's predictor under the byte in front
+//   p  = (p0 + 15 p1) / 16
+//   s  = value at p of the node's 17-point curve (linear between the two points around p)
+//   P(bit = 1) = (p + 3 s) / 4
+// and then p0 moves towards the bit by 1/4, p1 by 1/16, the two points of the curve by 1/64.
+// State per read: 256 + 256 x 256 predictors and 256 x 17 curve points = 137 KiB: ONE READ PER WORKGROUP
+// like the order-1 coder above, everything in LDS.  Encoding, the eight nodes of a byte are known in
+// advance and distinct (so are their curves): eight lanes fetch, mix and update them side by side and the
+// dependent chain is the interval arithmetic alone.  Decoding, the predictions of both children of a node
+// are fetched while its bit is decided; the curve's points are one more LDS round trip per bit.
+// (restated from its behaviour, pinned against the compiled reference by oracle/press_oracle.c:
+// po_rcms_encode / po_rcms_decode and tests/test_oracle_golden.py)
+
+namespace {
+struct RcmLds {
+	uint16_t mb1[65536];
+	uint16_t mb0[256];
+	uint16_t sse[256][17];
+};
+
+__device__ __forceinline__ void rcm_init(RcmLds &L)
+{
+	uint4 *m4 = reinterpret_cast<uint4 *>(L.mb1);
+	const uint32_t v = (1u << 15) | (1u << 31);
+	for (uint32_t i = threadIdx.x; i < 65536 / 8; i += RCC_WG)
+		m4[i] = make_uint4(v, v, v, v);
+	for (uint32_t i = threadIdx.x; i < 256; i += RCC_WG)
+		L.mb0[i] = 1u << 15;
+	for (uint32_t i = threadIdx.x; i < 256 * 17; i += RCC_WG) { // rccm_s.c:40-44
+		const uint32_t k = i % 17;
+		(&L.sse[0][0])[i] = (uint16_t) ((k << 12) - (k == 16));
+	}
+	__syncthreads();
+}
+
+// mbc_s.h:40 with the bit as a 64-bit unsigned (turborc_.h:421): the low 16 bits of
+// p - (((p - (bit ? 65536 : 0)) >> rate) + bit); for bit = 1 that is p + ceil((65536 - p) / 2^rate) - 1
+__device__ __forceinline__ uint32_t rcm_step(uint32_t p, uint32_t rate, uint32_t bit)
+{
+	return bit ? p + ((65536u - p + (1u << rate) - 1u) >> rate) - 1u : p - (p >> rate);
+}
+
+// P(bit = 1) out of the two predictions and the two points of the curve around their mix
+__device__ __forceinline__ uint32_t rcm_mix(uint32_t p, uint32_t x1, uint32_t x2)
+{
+	const int32_t sp = (int32_t) x1 + ((((int32_t) x2 - (int32_t) x1) * (int32_t) (p & 4095u)) >> 12);
+	return (uint32_t) (((int32_t) p + 3 * sp) >> 2);
+}
+} // namespace
+
+__global__ __launch_bounds__(RCC_WG) void k_rcm_encode(BatchArgs a)
+{
+	__shared__ __attribute__((aligned(16))) RcmLds L;
+	__shared__ uint32_t s_r;
+	const uint32_t lane = threadIdx.x;
+	for (;;) {
+		if (lane == 0)
+			s_r = atomicAdd(&a.ctl->ticket2, 1u);
+		__syncthreads();
+		const uint32_t r = s_r;
+		__syncthreads();
+		if (r >= a.nreads)
+			return;
+		const ReadMeta *m = a.meta + r;
+		if (m->status)
+			continue; // out_len = FAILED was written by k_ex_section
+		rcm_init(L);
+		const uint64_t n = m->nlow;
+		const uint32_t head = m->hdr + m->seclen;
+		const uint8_t *in = a.low_tmp + a.off[r];
+		RcOut o;
+		o.out = a.out + a.out_off[r] + head;
+		o.cap = a.out_off[r + 1] - a.out_off[r] - head;
+		o.pos = 0;
+		o.failed = false;
+		uint64_t low = 0, range = ~0ull;
+		const long long giveup = (long long) (n * 255 / 256) - 8;
+		bool raw = false;
+		uint32_t cx = 0;
+		uint32_t grp = 0; // 64 input bytes, one per lane
+		for (uint64_t i = 0; i < n && !raw; i++) {
+			if ((i & 63) == 0)
+				grp = i + lane < n ? in[i + lane] : 0u;
+			const uint32_t byte = (uint32_t) __builtin_amdgcn_readlane((int) grp, __builtin_amdgcn_readfirstlane((int) (i & 63)));
+			const uint32_t x = 0x100u | byte;
+			uint16_t *row = L.mb1 + cx * 256u;
+			// lane k < 8: the node of bit k, its two predictions, its curve
+			const uint32_t node = x >> ((lane & 7u) + 1u);
+			const uint32_t p0 = L.mb0[node], p1 = row[node];
+			const uint32_t p = (p0 + 15u * p1) >> 4;
+			uint16_t *cell = &L.sse[node][p >> 12];
+			const uint32_t x1 = cell[0], x2 = cell[1];
+			const uint32_t pm = rcm_mix(p, x1, x2);
+#pragma unroll
+			for (int k = 7; k >= 0; k--) {
+				if (range < RC_TOP) {
+					range <<= 32;
+					if (lane == 0)
+						rc_put32(o, (uint32_t) (low >> 32));
+					else
+						o.pos += 4;
+					low <<= 32;
+				}
+				const uint32_t pk = (uint32_t) __builtin_amdgcn_readlane((int) pm, k);
+				const uint64_t t = (range >> 16) * pk, before = low;
+				if ((x >> k) & 1u) {
+					range = t;
+				} else {
+					range -= t;
+					low += t;
+				}
+				if (before > low && lane == 0)
+					rc_carry(o);
+			}
+			if (lane < 8) {
+				const uint32_t bit = (x >> lane) & 1u;
+				L.mb0[node] = (uint16_t) rcm_step(p0, 2, bit);
+				row[node] = (uint16_t) rcm_step(p1, 4, bit);
+				cell[0] = (uint16_t) rcm_step(x1, 6, bit);
+				cell[1] = (uint16_t) rcm_step(x2, 6, bit);
+			}
+			cx = byte;
+			if ((long long) o.pos >= giveup)
+				raw = true; // rcutil_.h:161: stored instead
+		}
+		const bool failed0 = (bool) __shfl((int) o.failed, 0, 64);
+		if (raw) {
+			const bool fail = n > o.cap;
+			if (!fail)
+				for (uint64_t i = lane; i < n; i += RCC_WG)
+					o.out[i] = in[i];
+			if (lane == 0)
+				a.out_len[r] = fail ? ~0ull : (uint64_t) head + n;
+		} else if (lane == 0) {
+			o.failed = failed0;
+			if (range < RC_TOP) {
+				range <<= 32;
+				rc_put32(o, (uint32_t) (low >> 32));
+				low <<= 32;
+			}
+			const uint64_t before = low;
+			if (range > (1ull << 33)) {
+				low += 1ull << 32;
+				if (before > low)
+					rc_carry(o);
+				rc_put32(o, (uint32_t) (low >> 32));
+			} else {
+				low += 1;
+				if (before > low)
+					rc_carry(o);
+				rc_put32(o, (uint32_t) (low >> 32));
+				rc_put32(o, (uint32_t) low);
+			}
+			a.out_len[r] = o.failed ? ~0ull : (uint64_t) head + o.pos;
+		}
+		__syncthreads(); // the tables are free again
+	}
+}
+
+__global__ __launch_bounds__(RCC_WG) void k_rcm_decode(DecodeArgs a)
+{
+	__shared__ __attribute__((aligned(16))) RcmLds L;
+	__shared__ uint32_t s_r;
+	const uint32_t lane = threadIdx.x;
+	for (;;) {
+		if (lane == 0)
+			s_r = atomicAdd(&a.ctl->ticket2, 1u);
+		__syncthreads();
+		const uint32_t r = s_r;
+		__syncthreads();
+		if (r >= a.nreads)
+			return;
+		const ReadMeta *m = a.meta + r;
+		if (m->status)
+			continue;
+		rcm_init(L);
+		const uint64_t n = m->nlow;
+		const uint32_t head = m->hdr + m->seclen;
+		const uint8_t *in = a.in + a.in_off[r] + head;
+		const uint64_t len = a.in_len[r] - head;
+		uint8_t *out = a.low + a.off[r];
+		uint64_t pos = 0, range = ~0ull, code = 0;
+		// bytes past the end of the stream read as zeros (the reference reads whatever follows)
+		auto get32 = [&]() -> uint32_t {
+			uint32_t w = 0;
+			if (pos + 4 <= len) {
+				__builtin_memcpy(&w, in + pos, 4);
+			} else {
+				for (int b = 0; b < 4; b++)
+					if (pos + b < len)
+						w |= (uint32_t) in[pos + b] << (8 * b);
+			}
+			pos += 4;
+			return w;
+		};
+		uint32_t wn = get32(); // the next word is always in flight before it is needed
+		auto next32 = [&]() -> uint32_t {
+			const uint32_t w = wn;
+			wn = get32();
+			return w;
+		};
+		code = next32();
+		code = (code << 32) | next32();
+		uint16_t *row = L.mb1;
+		uint32_t acc = 0; // four decoded bytes
+		for (uint64_t i = 0; i < n; i++) {
+			uint32_t x = 1;
+			uint32_t p0 = L.mb0[1], p1 = row[1];
+#pragma unroll
+			for (int k = 7; k >= 0; k--) {
+				// the predictions of both children while this bit is being decided (a pair of neighbours each)
+				uint32_t c0 = 0, c1 = 0;
+				if (k) { // (memcpy: these words alias the 16-bit stores of the updates)
+					__builtin_memcpy(&c0, __builtin_assume_aligned(L.mb0 + 2 * x, 4), 4);
+					__builtin_memcpy(&c1, __builtin_assume_aligned(row + 2 * x, 4), 4);
+				}
+				const uint32_t p = (p0 + 15u * p1) >> 4;
+				uint16_t *cell = &L.sse[x][p >> 12];
+				const uint32_t x1 = cell[0], x2 = cell[1];
+				const uint32_t pm = rcm_mix(p, x1, x2);
+				if (range < RC_TOP) {
+					range <<= 32;
+					code = (code << 32) | next32();
+				}
+				const uint64_t t = (range >> 16) * pm;
+				const uint32_t bit = code < t ? 1u : 0u;
+				if (bit) {
+					range = t;
+				} else {
+					range -= t;
+					code -= t;
+				}
+				if (lane == 0) {
+					L.mb0[x] = (uint16_t) rcm_step(p0, 2, bit);
+					row[x] = (uint16_t) rcm_step(p1, 4, bit);
+					cell[0] = (uint16_t) rcm_step(x1, 6, bit);
+					cell[1] = (uint16_t) rcm_step(x2, 6, bit);
+				}
+				x = 2 * x + bit;
+				p0 = bit ? c0 >> 16 : c0 & 0xFFFFu;
+				p1 = bit ? c1 >> 16 : c1 & 0xFFFFu;
+			}
+			acc |= (x & 0xFFu) << (8 * ((uint32_t) i & 3u));
+			if (((uint32_t) i & 3u) == 3u || i + 1 == n) {
+				if (lane == 0)
+					for (uint32_t b = 0; b <= ((uint32_t) i & 3u); b++)
+						out[(i & ~3ull) + b] = (uint8_t) (acc >> (8 * b));
+				acc = 0;
+			}
+			row = L.mb1 + 256u * (x & 0xFFu); // the byte just decoded is the next context (rccm_.c:119)
+			// (lane 0's stores to the tables and every lane's later loads are DS operations of one wave: in order)
+		}
+		__syncthreads();
+	}
+}
+
+void launch_rcm_encode(const BatchArgs &a, hipStream_t s)
+{
+	(void) hipMemsetAsync(&a.ctl->ticket2, 0, 4, s);
+	hipLaunchKernelGGL(k_rcm_encode, dim3(a.nreads < 256u ? a.nreads : 256u), dim3(RCC_WG), 0, s, a);
+}
+
+void launch_rcm_decode(const DecodeArgs &a, hipStream_t s)
+{
+	(void) hipMemsetAsync(&a.ctl->ticket2, 0, 4, s);
+	hipLaunchKernelGGL(k_rcm_decode, dim3(a.nreads < 256u ? a.nreads : 256u), dim3(RCC_WG), 0, s, a);
 }
 
 void launch_rcc_encode(const BatchArgs &a, hipStream_t s)

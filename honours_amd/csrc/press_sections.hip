@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64) void k_ex_section(BatchArgs a, int fmt, int huf
 	if (need > cap)
 		return;
 	// press.c:4520,4636,4752: the b/sb/ss Huffman variants keep the section length in a uint16_t
-	if (huff && huff != 3 && fmt != EXF_VBE21 && seclen > 65535)
+	if (huff && fmt != EXF_VBE21 && seclen > 65535) // (the entropy-coded b/sb/ss forms keep this length in a uint16_t: press.c:4520, 6917)
 		return;
 	// ex_zd.c:411: the reference works in a 2n+1024-byte buffer
 	if (fmt == EXF_EXZD && need > 2ull * n + 1024)
@@ -468,6 +468,8 @@ void launch_ex_parse_huff(const DecodeArgs &a, int fmt, int ent, hipStream_t s)
 			launch_rcs_decode(a, s);
 		else if (ent == 3)
 			launch_rcc_decode(a, s);
+		else if (ent == 4)
+			launch_rcm_decode(a, s);
 		else
 			launch_huff_decode(a, a.huf_minlen, s);
 		ktime_end(1, s);

@@ -23,7 +23,7 @@ METHODS = {
     "vbe21_zd": 5, "vbbe21_zd": 6, "vbsbe21_zd": 7, "vbsse21_zd": 8,
     "shuffman_vbe21_zd": 9, "shuffman_vbbe21_zd": 10, "shuffman_vbsbe21_zd": 11,
     "shuffman_vbsse21_zd": 12, "hasgam_vbsse21_zdq": 13, "zstd_hasgam_vbsse21_zdq": 14,
-    "slow5_svb_zd": 15, "rc_vbe21_zd": 16, "rcc_vbe21_zd": 17,
+    "slow5_svb_zd": 15, "rc_vbe21_zd": 16, "rcc_vbe21_zd": 17, "rccm_vbbe21_zd": 18,
 }
 BATCH_METHODS = [m for m in METHODS if not m.startswith("zstd_")]
 FAILED = (1 << 64) - 1
@@ -62,6 +62,7 @@ _SYMS = {
     "rc_vbe21_zd": ("rc_vbe21_zd_bound_16", "rc_vbe21_zd_press_16", "rc_vbe21_zd_depress_16", "vb"),
     # ... order 1 (one read per workgroup)
     "rcc_vbe21_zd": ("rcc_vbe21_zd_bound_16", "rcc_vbe21_zd_press_16", "rcc_vbe21_zd_depress_16", "vb"),
+    "rccm_vbbe21_zd": ("rccm_vbbe21_zd_bound_16", "rccm_vbbe21_zd_press_16", "rccm_vbbe21_zd_depress_16", "vb"),
 }
 
 # every symbol include/press_hip.h declares (checked by tests/test_abi_symbols.py)

@@ -141,6 +141,12 @@ void rc_vbe21_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *n
 uint64_t rcc_vbe21_zd_bound_16(uint32_t nin);
 void rcc_vbe21_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
 void rcc_vbe21_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
+/* ---- vbbe21 + order 1-0 context mixing with secondary estimation (TurboRC rcmsenc / rcmsdec, rccm_.c:79,
+ * instantiated by rccm_s.c): press.c:6901-7000 (the thesis's "rc01s-vbbe21-zd").  Same calling
+ * shape as rc_vbe21_zd: *nout of depress in = the exact sample count (press.c:6986). ---- */
+uint64_t rccm_vbbe21_zd_bound_16(uint32_t nin);
+void rccm_vbbe21_zd_press_16(const int16_t *in, uint32_t nin, uint8_t *out, uint64_t *nout);
+void rccm_vbbe21_zd_depress_16(uint8_t *in, uint64_t nin, int16_t *out, uint32_t *nout);
 
 /* ---- ex-zd v0: press.h:960-964 (press.c:8461-8500 over ex_zd.c:403,495) ---- */
 uint64_t hasgam_vbsse21_zdq_bound_16(uint32_t nin);
@@ -188,7 +194,8 @@ enum press_hip_method {
 	PRESS_HIP_SLOW5_SVB_ZD     = 15, /* BLOW5's signal codec (section 3) */
 	PRESS_HIP_RC_VBE21_ZD      = 16, /* vbe21 + order-0 range coder: one read per lane (serial format) */
 	PRESS_HIP_RCC_VBE21_ZD     = 17, /* vbe21 + order-1 range coder: one read per workgroup, its 128 KiB of state in LDS */
-	PRESS_HIP_NMETHODS         = 18
+	PRESS_HIP_RCCM_VBBE21_ZD   = 18, /* vbbe21 + order 1-0 context mixing + SSE: one read per workgroup, 137 KiB of state in LDS */
+	PRESS_HIP_NMETHODS         = 19
 };
 
 #define PRESS_HIP_OK        0

@@ -27,7 +27,8 @@ enum press_method {
 	PM_SLOW5_SVB_ZD     = 15, /* BLOW5 signal codec "svb-zd": slow5lib slow5_press.c:1054,1110 */
 	PM_RC_VBE21_ZD      = 16, /* vbe21 + order-0 range coder (TurboRC rcsenc)  press.h:712-716 */
 	PM_RCC_VBE21_ZD     = 17, /* vbe21 + order-1 range coder (TurboRC rccsenc) press.h (press.c:5510-5580) */
-	PM_NMETHODS         = 18
+	PM_RCCM_VBBE21_ZD   = 18, /* vbbe21 + order 1-0 context mixing with SSE (TurboRC rcmsenc) press.c:6901-7000 */
+	PM_NMETHODS         = 19
 };
 
 #endif

@@ -695,6 +695,7 @@ uint64_t po_bound(int method, uint32_t n)
 	case PM_SHUFF_VBSSE21_ZD: return vb_zd_bound(n);                           /* press.c:3411,4409 */
 	case PM_RC_VBE21_ZD:      return vb_zd_bound(n);                           /* press.c:5422 */
 	case PM_RCC_VBE21_ZD:     return vb_zd_bound(n);                           /* press.c:5510 */
+	case PM_RCCM_VBBE21_ZD:   return vb_zd_bound(n);                           /* press.c:6901 */
 	case PM_HASGAM_ZDQ:       return svb32_bound((uint32_t) vb_zd_bound(n));   /* press.c:8461 */
 	case PM_ZSTD_HASGAM_ZDQ:  return zstd_bound_(svb32_bound((uint32_t) vb_zd_bound(n)));
 	/* slow5_press.c:1037: __slow5_streamvbyte_max_compressedbytes(n) (streamvbyte.h:31, no padding) + the u32 count */
@@ -878,11 +879,174 @@ static void rc_decode(const uint8_t *in, uint64_t len, uint64_t n, uint8_t *out,
 void po_rcs_decode(const uint8_t *in, uint64_t len, uint64_t n, uint8_t *out) { rc_decode(in, len, n, out, 0); }
 void po_rccs_decode(const uint8_t *in, uint64_t len, uint64_t n, uint8_t *out) { rc_decode(in, len, n, out, 1); }
 
+/*
+ * rcmsenc / rcmsdec (Turbo-Range-Coder rccm_.c:79-121 instantiated by rccm_s.c:46-48: 16-bit
+ * probabilities, simple predictor with the rate as parameter): the same range coder, every bit coded
+ * under a mix of two predictions with a secondary estimation on top (mbc.h:185-193 mbum_p):
+ *   p0 = order-0 predictor of the bit's node, p1 = the same node under the byte in front (order 1)
+ *   p  = (p0 + 15 p1) / 16
+ *   s  = value at p of the 17-point curve of the node (linear between the two points around p)
+ *   P(bit = 1) = (p + 3 s) / 4
+ * then p0 moves towards the bit by 1/4, p1 by 1/16, the two points of the curve by 1/64
+ * (mbc.h:195-209, 230-235; mbc_s.h:40; mbu_updates mbc.h:94).  The range is renormalised in front of
+ * every bit (turborc_.h:431-434).
+ */
+struct rcm_model {
+	uint16_t mb0[256];
+	uint16_t mb1[256][256];
+	uint16_t sse[256][17];
+};
+
+static struct rcm_model *rcm_new(void)
+{
+	struct rcm_model *m = malloc(sizeof *m);
+	int i, j;
+	for (i = 0; i < 256; i++) {
+		m->mb0[i] = 1u << 15;
+		for (j = 0; j < 256; j++)
+			m->mb1[i][j] = 1u << 15;
+		for (j = 0; j <= 16; j++) /* rccm_s.c:40-44 */
+			m->sse[i][j] = (uint16_t) ((j << 12) - (j == 16));
+	}
+	return m;
+}
+
+/* probability of a 1 under node x with `cx` the byte in front; *pp0, *pp1: the two predictions; *cell:
+ * the lower one of the curve's two points */
+static uint32_t rcm_p(struct rcm_model *m, unsigned cx, unsigned x, uint32_t *pp0, uint32_t *pp1, uint16_t **cell)
+{
+	const uint32_t p0 = m->mb0[x], p1 = m->mb1[cx][x];
+	const int32_t p = (int32_t) ((p0 + 15u * p1) >> 4);
+	uint16_t *c = &m->sse[x][p >> 12];
+	const int32_t x1 = c[0];
+	const int32_t sp = x1 + ((((int32_t) c[1] - x1) * (p & 4095)) >> 12);
+	*pp0 = p0;
+	*pp1 = p1;
+	*cell = c;
+	return (uint32_t) ((p + 3 * sp) >> 2);
+}
+
+static uint16_t rcm_step(uint32_t p, unsigned rate, unsigned bit)
+{
+	/* mbc_s.h:40 with the bit as a 64-bit unsigned (turborc_.h:421): the low 16 bits of
+	 * p - (((p - (bit ? 65536 : 0)) >> rate) + bit) */
+	const uint64_t t = (uint64_t) p - (bit ? 65536u : 0u);
+	return (uint16_t) (p - ((t >> rate) + bit));
+}
+
+static void rcm_update(struct rcm_model *m, unsigned cx, unsigned x, uint32_t p0, uint32_t p1, uint16_t *cell, unsigned bit)
+{
+	m->mb0[x] = rcm_step(p0, 2, bit);
+	m->mb1[cx][x] = rcm_step(p1, 4, bit);
+	cell[0] = rcm_step(cell[0], 6, bit);
+	cell[1] = rcm_step(cell[1], 6, bit);
+}
+
+/* out must have room for n + n/2 + 64 bytes; returns the stream length */
+uint64_t po_rcms_encode(const uint8_t *in, uint64_t n, uint8_t *out)
+{
+	struct rc_enc c = { 0, ~(uint64_t) 0, out, 0 };
+	struct rcm_model *m = rcm_new();
+	const int64_t giveup = (int64_t) (n * 255 / 256) - 8; /* rcutil_.h:161 */
+	unsigned cx = 0;
+	uint64_t i;
+	int k;
+	for (i = 0; i < n; i++) {
+		const unsigned x = 0x100u | in[i];
+		for (k = 7; k >= 0; k--) {
+			const unsigned node = x >> (k + 1), bit = (x >> k) & 1u;
+			uint32_t p0, p1;
+			uint16_t *cell;
+			const uint32_t pm = rcm_p(m, cx, node, &p0, &p1, &cell);
+			uint64_t t, before;
+			rc_norm(&c);
+			t = (c.range >> 16) * pm;
+			before = c.low;
+			if (bit) {
+				c.range = t;
+			} else {
+				c.range -= t;
+				c.low += t;
+			}
+			if (before > c.low)
+				rc_carry(&c);
+			rcm_update(m, cx, node, p0, p1, cell, bit);
+		}
+		cx = in[i];
+		if ((int64_t) c.pos >= giveup) {
+			memcpy(out, in, n);
+			free(m);
+			return n;
+		}
+	}
+	free(m);
+	rc_norm(&c);
+	{
+		const uint64_t before = c.low;
+		if (c.range > ((uint64_t) 1 << 33)) {
+			c.low += (uint64_t) 1 << 32;
+			if (before > c.low)
+				rc_carry(&c);
+			rc_put32(&c, (uint32_t) (c.low >> 32));
+		} else {
+			c.low += 1;
+			if (before > c.low)
+				rc_carry(&c);
+			rc_put32(&c, (uint32_t) (c.low >> 32));
+			rc_put32(&c, (uint32_t) c.low);
+		}
+	}
+	return c.pos;
+}
+
+/* decodes n bytes; bytes past `len` read as zeros (the reference reads whatever follows) */
+void po_rcms_decode(const uint8_t *in, uint64_t len, uint64_t n, uint8_t *out)
+{
+	uint64_t range = ~(uint64_t) 0, code = 0, pos = 0, i;
+	struct rcm_model *m = rcm_new();
+	unsigned cx = 0;
+	int k;
+	for (k = 0; k < 2; k++) {
+		const uint32_t w = rc_get32(in, len, pos);
+		pos += 4;
+		code = (code << 32) | w;
+	}
+	for (i = 0; i < n; i++) {
+		unsigned x = 1;
+		for (k = 7; k >= 0; k--) {
+			uint32_t p0, p1;
+			uint16_t *cell;
+			const uint32_t pm = rcm_p(m, cx, x, &p0, &p1, &cell);
+			uint64_t t;
+			unsigned bit;
+			if (range < ((uint64_t) 1 << 32)) {
+				const uint32_t w = rc_get32(in, len, pos);
+				pos += 4;
+				range <<= 32;
+				code = (code << 32) | w;
+			}
+			t = (range >> 16) * pm;
+			bit = code < t;
+			if (bit) {
+				range = t;
+			} else {
+				range -= t;
+				code -= t;
+			}
+			rcm_update(m, cx, x, p0, p1, cell, bit);
+			x = 2 * x + bit;
+		}
+		out[i] = (uint8_t) x;
+		cx = (uint8_t) x;
+	}
+	free(m);
+}
+
 static enum exfmt exfmt_of(int method)
 {
 	switch (method) {
 	case PM_VBE21_ZD: case PM_SHUFF_VBE21_ZD: case PM_RC_VBE21_ZD: case PM_RCC_VBE21_ZD: return EX_VBE21;
-	case PM_VBBE21_ZD: case PM_SHUFF_VBBE21_ZD:   return EX_VBBE21;
+	case PM_VBBE21_ZD: case PM_SHUFF_VBBE21_ZD: case PM_RCCM_VBBE21_ZD: return EX_VBBE21;
 	case PM_VBSBE21_ZD: case PM_SHUFF_VBSBE21_ZD: return EX_VBSBE21;
 	case PM_VBSSE21_ZD: case PM_SHUFF_VBSSE21_ZD: return EX_VBSSE21;
 	default:                                      return EX_EXZD;
@@ -919,16 +1083,16 @@ static int vb_family_press(int method, const int16_t *in, uint32_t n, uint8_t *o
 	seclen = exsec_write(f, &e, sec);
 	nlow = lowbytes_write(z + 1, n - 1, low);
 	/* press.c:4520 etc: the b/sb/ss Huffman variants keep the section length in a uint16_t */
-	if (is_shuff(method) && f != EX_VBE21 && seclen > 65535)
+	if ((is_shuff(method) || method == PM_RCCM_VBBE21_ZD) && f != EX_VBE21 && seclen > 65535) /* (:6917 for rccm) */
 		goto done;
 	if (2 + seclen > cap)
 		goto done;
 	put_u16(out, z[0]);
 	memcpy(out + 2, sec, seclen);
 	o = 2 + seclen;
-	if (method == PM_RC_VBE21_ZD || method == PM_RCC_VBE21_ZD) { /* press.c:5427 / :5547: the one-byte values through rcsenc / rccsenc */
+	if (method == PM_RC_VBE21_ZD || method == PM_RCC_VBE21_ZD || method == PM_RCCM_VBBE21_ZD) { /* press.c:5427 / :5547 / :6946: the one-byte values through rcsenc / rccsenc / rcmsenc */
 		uint8_t *tmp = malloc((size_t) nlow + nlow / 2 + 64);
-		const uint64_t rl = rc_encode(low, nlow, tmp, method == PM_RCC_VBE21_ZD);
+		const uint64_t rl = method == PM_RCCM_VBBE21_ZD ? po_rcms_encode(low, nlow, tmp) : rc_encode(low, nlow, tmp, method == PM_RCC_VBE21_ZD);
 		if (o + rl > cap) {
 			free(tmp);
 			goto done;
@@ -976,12 +1140,15 @@ static int vb_family_depress(int method, const uint8_t *in, uint64_t nbytes, uin
 	}
 	z = malloc(((size_t) n + 1) * sizeof *z);
 	z[0] = get_u16(in);
-	if (method == PM_RC_VBE21_ZD || method == PM_RCC_VBE21_ZD) { /* press.c:5465 / :5573: n is the exact sample count, so the byte count is known */
+	if (method == PM_RC_VBE21_ZD || method == PM_RCC_VBE21_ZD || method == PM_RCCM_VBBE21_ZD) { /* press.c:5465 / :5573 / :6987: n is the exact sample count, so the byte count is known */
 		if ((uint64_t) e.n + 1 > n)
 			goto done;
 		nlow = (uint64_t) n - 1 - e.n;
 		low = malloc((size_t) nlow + 1);
-		rc_decode(in + 2 + seclen, nbytes - 2 - seclen, nlow, low, method == PM_RCC_VBE21_ZD);
+		if (method == PM_RCCM_VBBE21_ZD)
+			po_rcms_decode(in + 2 + seclen, nbytes - 2 - seclen, nlow, low);
+		else
+			rc_decode(in + 2 + seclen, nbytes - 2 - seclen, nlow, low, method == PM_RCC_VBE21_ZD);
 		lowp = low;
 	} else if (is_shuff(method)) {
 		uint32_t got = 0;
@@ -1193,7 +1360,7 @@ int po_press(int method, const int16_t *in, uint32_t n, uint8_t *out, uint64_t *
 	case PM_VBE21_ZD: case PM_VBBE21_ZD: case PM_VBSBE21_ZD: case PM_VBSSE21_ZD:
 	case PM_SHUFF_VBE21_ZD: case PM_SHUFF_VBBE21_ZD: case PM_SHUFF_VBSBE21_ZD:
 	case PM_SHUFF_VBSSE21_ZD:
-	case PM_RC_VBE21_ZD: case PM_RCC_VBE21_ZD:
+	case PM_RC_VBE21_ZD: case PM_RCC_VBE21_ZD: case PM_RCCM_VBBE21_ZD:
 		return vb_family_press(method, in, n, out, nout);
 	case PM_SLOW5_SVB_ZD: {
 		/* slow5_press.c:1054 ptr_compress_svb_zd: samples widened to int32, zig-zag delta in 32 bits
@@ -1248,7 +1415,7 @@ int po_depress(int method, const uint8_t *in, uint64_t nbytes, uint32_t n,
 	case PM_VBE21_ZD: case PM_VBBE21_ZD: case PM_VBSBE21_ZD: case PM_VBSSE21_ZD:
 	case PM_SHUFF_VBE21_ZD: case PM_SHUFF_VBBE21_ZD: case PM_SHUFF_VBSBE21_ZD:
 	case PM_SHUFF_VBSSE21_ZD:
-	case PM_RC_VBE21_ZD: case PM_RCC_VBE21_ZD:
+	case PM_RC_VBE21_ZD: case PM_RCC_VBE21_ZD: case PM_RCCM_VBBE21_ZD:
 		return vb_family_depress(method, in, nbytes, n, out, nout);
 	case PM_SLOW5_SVB_ZD: {
 		/* slow5_press.c:1110 ptr_depress_svb_zd -> :1085 ptr_depress_svb: the count comes from

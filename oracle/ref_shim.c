@@ -87,6 +87,7 @@ uint64_t ref_bound(int method, uint32_t n)
 	case PM_SLOW5_SVB_ZD:     return (uint64_t) (n + 3) / 4 + (uint64_t) n * 4 + 4; /* slow5_press.c:1037 */
 	case PM_RC_VBE21_ZD:      return rc_vbe21_zd_bound_16(n);
 	case PM_RCC_VBE21_ZD:     return rcc_vbe21_zd_bound_16(n);
+	case PM_RCCM_VBBE21_ZD:   return rccm_vbbe21_zd_bound_16(n);
 	}
 	return 0;
 }
@@ -113,6 +114,7 @@ int ref_press(int method, const int16_t *in, uint32_t n, uint8_t *out,
 	case PM_ZSTD_HASGAM_ZDQ:  return zstd_hasgam_vbsse21_zdq_press_16(in, n, out, nout);
 	case PM_RC_VBE21_ZD:      rc_vbe21_zd_press_16(in, n, out, nout); return 0;
 	case PM_RCC_VBE21_ZD:     rcc_vbe21_zd_press_16(in, n, out, nout); return 0;
+	case PM_RCCM_VBBE21_ZD:   rccm_vbbe21_zd_press_16(in, n, out, nout); return 0;
 	case PM_SLOW5_SVB_ZD: { /* what slow5_rec_to_mem does with a read's signal (slow5.c:3948) */
 		size_t len = 0;
 		void *buf = slow5_ptr_compress_solo(SLOW5_COMPRESS_SVB_ZD, in, (size_t) n * sizeof *in, &len);
@@ -157,6 +159,7 @@ int ref_depress(int method, uint8_t *in, uint64_t nbytes, uint32_t n,
 	case PM_ZSTD_HASGAM_ZDQ:  ret = zstd_hasgam_vbsse21_zdq_depress_16(in, nbytes, out, nout); break;
 	case PM_RC_VBE21_ZD:      rc_vbe21_zd_depress_16(in, nbytes, out, nout); break;
 	case PM_RCC_VBE21_ZD:     rcc_vbe21_zd_depress_16(in, nbytes, out, nout); break;
+	case PM_RCCM_VBBE21_ZD:   rccm_vbbe21_zd_depress_16(in, nbytes, out, nout); break;
 	case PM_SLOW5_SVB_ZD: {
 		size_t len = 0;
 		void *buf = slow5_ptr_depress_solo(SLOW5_COMPRESS_SVB_ZD, in, (size_t) nbytes, &len);

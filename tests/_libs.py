@@ -24,8 +24,30 @@ METHODS = {
     "slow5_svb_zd": 15,  # BLOW5's signal codec (slow5lib svb-zd), SURVEY 8f-2
     "rc_vbe21_zd": 16,   # vbe21 + TurboRC order-0 range coder, SURVEY 8f-1
     "rcc_vbe21_zd": 17,  # vbe21 + TurboRC order-1 range coder, SURVEY 8f-1
+    "rccm_vbbe21_zd": 18,  # vbbe21 + TurboRC order 1-0 context mixing + SSE, SURVEY 8f-4
 }
 DETERMINISTIC = [m for m in METHODS if not m.startswith("zstd_")]
+RC_FAMILY = ("rc_vbe21_zd", "rcc_vbe21_zd", "rccm_vbbe21_zd")
+
+
+def rc_stored_raw(method, stream, n):
+    """TurboRC stores tiny / incompressible inputs raw (rcutil_.h:161: once the coder's output reaches
+    n*255/256 - 8 bytes) and nothing tells its decoder: such streams are outside the reference's lossless
+    domain (its own decoder may even abort on them).  True if `stream` of an n-sample read is one."""
+    nex = int.from_bytes(stream[2:6], "little")
+    if method == "rccm_vbbe21_zd":  # vbbe21 section (press.c:6931-6940)
+        sec = 4
+        if nex > 1:
+            lp = int.from_bytes(stream[2 + sec:6 + sec], "little")
+            sec += 4 + lp
+            lv = int.from_bytes(stream[2 + sec:6 + sec], "little")
+            sec += 4 + lv
+        elif nex == 1:
+            sec += 6
+    else:                           # vbe21 section: u32 positions, u16 values
+        sec = 4 + 6 * nex
+    nlow = n - 1 - nex
+    return nlow > 0 and len(stream) - 2 - sec == nlow
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 

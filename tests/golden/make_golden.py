@@ -39,6 +39,11 @@ import _libs  # noqa: E402
 from honours_amd import synth  # noqa: E402
 
 REF = "/root/reference"
+# The range-coder methods store a few dozen samples raw without telling their decoder (TurboRC
+# rcutil_.h:161) and the reference aborts on some of the tiny inputs below (wrap8 with rcc_vbe21_zd):
+# reads that short are outside these methods' domain - their known answers are three_reads.json and the
+# synthetic reads of 64 samples and more.
+RCFAM = ("rc_", "rcc_", "rccm_")
 
 
 def quiet_stderr():
@@ -128,7 +133,7 @@ def main():
         sig = np.array(vals, dtype=np.int16)
         ent = {"name": name, "input": [int(v) for v in sig], "streams": {}}
         for m in _libs.DETERMINISTIC:
-            if not in_valid_domain(m, sig):
+            if not in_valid_domain(m, sig) or m.startswith(RCFAM):
                 continue
             ret, c = ref.press(m, sig, cap=int(ref.bound(m, len(sig))) + 16 * len(sig) + 64)
             assert ret == 0, (name, m, ret)
@@ -165,7 +170,7 @@ def main():
         ent = {"seed": seed, "read": r, "n": int(n), "first": f, "sha256_32_signal": sha(sig.tobytes()),
                "methods": {}}
         for m in _libs.METHODS:
-            if not in_valid_domain(m, sig):
+            if not in_valid_domain(m, sig) or (m.startswith(RCFAM) and n < 64):
                 continue
             ret, c = ref.press(m, sig)
             assert ret == 0, (m, n)
