@@ -586,15 +586,16 @@ __device__ __forceinline__ void wave_lds_sync()
 
 constexpr uint32_t EMIT_STG = 3328; // staging bytes per wave: 52 per lane (NA12878: 47.4 on average, 64 at most)
 
-// The codes that start in [p, L) of the column, at most nmine of them: the DELTA each symbol stands for
-// (zig-zag undone, one signed byte) to wp[0 ..] (LDS staging or the one-byte stream's place).
+// The first nmine codes from bit p of the column on: the DELTA each symbol stands for (zig-zag undone, one
+// signed byte) to wp[0 ..] (LDS staging or the one-byte stream's place).  k_huf_sync counted the codes that
+// start in the subsequence, so the count alone ends the loop: no position is checked against the end.
 // lut entry (HuffDev::lut32): d1 | adv << 8 | d2 << 16 | len1 << 24 | HUF_TWO; long codes through lut2.
 template <typename WP>
 __device__ __forceinline__ void emit_codes(const uint32_t *col, const uint32_t *lut, const uint16_t *lut2,
-					   const HuffDev *hd, uint32_t p, uint32_t L, uint32_t nmine, WP wp)
+					   const HuffDev *hd, uint32_t p, uint32_t nmine, WP wp)
 {
-	// a long code (13 .. 24 bits) as a one-code entry; 0: the bits are no code (cannot come up in
-	// front of L: k_huf_sync stopped counting there)
+	// a long code (13 .. 24 bits) as a one-code entry; 0: the bits are no code (cannot come up among
+	// the codes k_huf_sync counted)
 	auto long_entry = [&](uint32_t e, uint32_t wnd) -> uint32_t {
 		if (e == 0xFFFFFFFFu) {
 			const uint32_t t = trie_code(hd, wnd);
@@ -604,65 +605,40 @@ __device__ __forceinline__ void emit_codes(const uint32_t *col, const uint32_t *
 		return e2 == 0xFFFFu ? 0u : (((uint32_t) unzz8(e2 & 0xFFu) & 0xFFu) | (e2 & 0x1F00u) | ((e2 & 0x1F00u) << 16));
 	};
 	uint32_t q = 0; // symbols written
-	{
-		// both codes of a look-up start below L while p <= Lm, and the quota has room for two while q <= qm
-		int32_t Lm = (int32_t) L - HUF_LUT_BITS;
-		const int32_t qm = (int32_t) nmine - 2;
-		uint32_t j = p >> 5;
-		uint32_t w0 = col[j * 64], w1 = col[(j + 1) * 64];
-		for (;;) {
-			const bool act = (int32_t) p <= Lm && (int32_t) q <= qm;
-			if (!any64(act))
-				break;
-			if (act) { // (exec-masked body: the lanes that are done do nothing)
-				const uint32_t w2 = col[(j + 2) * 64]; // (the row behind the last column keeps this read inside the array)
-				const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p);
-				uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
-				if (e >= HUF_LONG) { // rare (one code in 200): longer than 12 bits
-					e = long_entry(e, wnd);
-					if (e == 0 || p + ((e >> 8) & 0x1Fu) > L) {
-						e = 0;
-						Lm = -1; // the careful loop decides
-					}
-				}
-				if (e) {
-					wp[q] = (uint8_t) e;
-					if (e & HUF_TWO)
-						wp[q + 1] = (uint8_t) (e >> 16);
-					q += 1u + ((e >> 29) & 1u);
-					p += (e >> 8) & 0x1Fu;
-				}
-				const uint32_t jn = p >> 5;
-				if (jn != j) {
-					w0 = w1;
-					w1 = w2;
-				}
-				j = jn;
-			}
-		}
-	}
-	for (;;) { // the careful loop: the last codes of the subsequence / of the quota
-		const bool act = p < L && q < nmine;
+	uint32_t j = p >> 5;
+	uint32_t w0 = col[j * 64], w1 = col[(j + 1) * 64];
+	for (;;) { // while the count has room for two
+		const bool act = q + 2 <= nmine;
 		if (!any64(act))
 			break;
-		const uint32_t pp = act ? p : 0u;
-		const uint32_t j = pp >> 5;
-		const uint32_t wnd = __builtin_amdgcn_alignbit(col[(j + 1) * 64], col[j * 64], pp);
-		uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
-		if (any64(act && e >= HUF_LONG)) {
-			if (act && e >= HUF_LONG)
+		if (act) { // (exec-masked body: the lanes that are done do nothing)
+			const uint32_t w2 = col[(j + 2) * 64]; // (the row behind the last column keeps this read inside the array)
+			const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p);
+			uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
+			if (e >= HUF_LONG) { // rare (one code in 200): longer than 12 bits
 				e = long_entry(e, wnd);
-		}
-		const uint32_t len1 = (e >> 24) & 0x1Fu;
-		// the second code counts only if it starts inside and the quota has room
-		const bool two = (e & HUF_TWO) && pp + len1 < L && q + 2 <= nmine;
-		if (act) {
+				if (e == 0)
+					nmine = q; // (cannot happen: stop rather than spin)
+			}
 			wp[q] = (uint8_t) e;
-			if (two)
+			if (e & HUF_TWO)
 				wp[q + 1] = (uint8_t) (e >> 16);
-			p += two ? ((e >> 8) & 0x1Fu) : len1;
-			q += two ? 2u : 1u;
+			q += 1u + ((e >> 29) & 1u);
+			p += (e >> 8) & 0x1Fu;
+			const uint32_t jn = p >> 5;
+			if (jn != j) {
+				w0 = w1;
+				w1 = w2;
+			}
+			j = jn;
 		}
+	}
+	if (q < nmine) { // the last code of an odd count
+		const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p);
+		uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
+		if (e >= HUF_LONG)
+			e = long_entry(e, wnd);
+		wp[q] = (uint8_t) e;
 	}
 }
 
@@ -927,7 +903,6 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 		const uint64_t roff = dp->low; // the read's slot: samples in a.sig, one-byte values in a.low, exceptions
 		uint8_t *low = a.low + roff;
 		col_load<NDW>(col, src, (int32_t) tid * (OWN / 8), 0, (int32_t) ((nbits_t + 7) >> 3));
-		const uint32_t nb = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN);
 		const uint32_t rec = has ? a.hrec[(uint64_t) k * HT + tid] : R_END;
 		const uint32_t cnt = rec >> 8;
 		const uint32_t inc = wave_scan(cnt);
@@ -947,13 +922,10 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 		// the wave delivers values [obase, obase + wsum) of the read, cut at `want`
 		const uint32_t quota = obase >= want ? 0u : (wsum < want - (uint32_t) obase ? wsum : want - (uint32_t) obase);
 		const uint32_t ex = inc - cnt; // codes of the wave in front of this lane
-		const uint32_t nmine = ex >= quota ? 0u : (cnt < quota - ex ? cnt : quota - ex);
-		uint8_t *dst = low + obase;
 		const uint32_t f = rec & 0xFFu;
 		const uint32_t p0 = f == R_END ? 0u : f;
-		uint32_t L = (uint32_t) OWN < nb ? (uint32_t) OWN : nb;
-		if (f == R_END || nmine == 0)
-			L = 0;
+		const uint32_t nmine = (ex >= quota || f == R_END) ? 0u : (cnt < quota - ex ? cnt : quota - ex);
+		uint8_t *dst = low + obase;
 		EmitRead R = {};
 		if (fused) {
 			const ReadMeta *m = a.meta + uniform(dp->read);
@@ -968,7 +940,7 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 		// symbols go to the wave's staging buffer in their final order; a wave that holds more codes than
 		// the buffer takes (cannot happen with 5.4-bit codes on average) stores them byte by byte instead
 		if (wsum <= EMIT_STG) {
-			emit_codes(col, lut, lut2, a.huff, p0, L, nmine, stg + ex);
+			emit_codes(col, lut, lut2, a.huff, p0, nmine, stg + ex);
 			wave_lds_sync();
 			if (fused) {
 				if (quota)
@@ -989,7 +961,7 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 			}
 			wave_lds_sync(); // staging is free again
 		} else {
-			emit_codes(col, lut, lut2, a.huff, p0, L, nmine, dst + ex);
+			emit_codes(col, lut, lut2, a.huff, p0, nmine, dst + ex);
 			if (fused && quota) {
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the wave reads back what its lanes wrote
 				__builtin_amdgcn_wave_barrier();
