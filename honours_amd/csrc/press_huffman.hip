@@ -738,42 +738,60 @@ __device__ __forceinline__ void expand8s(uint2 dd, uint32_t v[4])
 		v[h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(i16x2, t[h]) >> eight);
 }
 
-// The deltas of the wave's values [L0, L0 + quota) are in src (LDS staging: src[l - L0]; or, GLOBAL, the
-// place of the read's one-byte stream: src[l]): write the samples they and their exceptions make.
-// B0 = sum of the deltas of the values in front of L0 (mod 2^16).
-template <bool GLOBAL>
-__device__ __forceinline__ void emit_samples(const uint8_t *src, const EmitRead &R, uint32_t L0, uint32_t quota,
-					     uint32_t B0, uint32_t lane)
+struct EmitPlan { // where a wave's samples lie and what they start from (wave-uniform but for pe)
+	uint32_t L0, L1;   // the wave's one-byte values
+	uint32_t Ea, ecnt; // its exceptions: [Ea, Ea + ecnt)
+	uint32_t Ia, Ib;   // its samples
+	uint32_t base;     // value of the sample in front of Ia
+	uint32_t pe;       // lane e < ecnt <= 64: position of exception Ea + e
+};
+
+// What emit_samples needs besides the values themselves.  B0 = sum of the deltas of the values in front of L0
+// (mod 2^16); key = pos[lane] - lane of the read's first 64 exceptions, loaded by the caller BEFORE the wave
+// decodes its codes (the load is under way meanwhile).
+__device__ __forceinline__ EmitPlan emit_plan(const EmitRead &R, uint32_t L0, uint32_t quota, uint32_t B0, uint32_t lane,
+					      uint32_t key)
 {
-	const uint32_t L1 = L0 + quota;
+	EmitPlan P;
+	P.L0 = L0;
+	P.L1 = L0 + quota;
 	const uint32_t nex = R.nex;
-	const bool lastw = L1 == R.nlow;
+	const bool lastw = P.L1 == R.nlow;
 	// exceptions in front of the wave's first / behind its last sample
 	uint32_t Ea = 0, Eb = 0;
 	if (nex && nex <= 64) {
-		const uint32_t key = lane < nex ? R.pos[lane] - lane : 0xFFFFFFFFu;
-		Ea = (uint32_t) __popcll(__ballot(key < L0));
-		Eb = (uint32_t) __popcll(__ballot(key < L1));
+		Ea = (uint32_t) __popcll(__ballot(key < P.L0));
+		Eb = (uint32_t) __popcll(__ballot(key < P.L1));
 	} else if (nex) {
-		Ea = keys_below(R.pos, nex, L0);
-		Eb = keys_below(R.pos, nex, L1);
+		Ea = keys_below(R.pos, nex, P.L0);
+		Eb = keys_below(R.pos, nex, P.L1);
 	}
 	if (lastw)
 		Eb = nex;
-	const uint32_t ecnt = Eb - Ea;
-	const uint32_t Ia = L0 ? L0 + Ea + 1 : 0u;
-	const uint32_t Ib = L1 + Eb + 1;
-	// value of the sample in front of Ia
-	uint32_t base = 0;
+	P.Ea = Ea;
+	P.ecnt = Eb - Ea;
+	P.Ia = L0 ? L0 + Ea + 1 : 0u;
+	P.Ib = P.L1 + Eb + 1;
+	P.base = 0;
 	if (L0) {
-		base = unzz16(R.zd0) + B0;
+		P.base = unzz16(R.zd0) + B0;
 		if (Ea) {
 			const uint32_t pv = uniform(R.val[Ea - 1]);
-			base += (pv >> 16) + unzz16(pv & 0xFFFFu);
+			P.base += (pv >> 16) + unzz16(pv & 0xFFFFu);
 		}
 	}
 	// the wave's exceptions, one per lane (more than 64: searched where needed)
-	const uint32_t pe = (ecnt <= 64 && lane < ecnt) ? R.pos[Ea + lane] : 0xFFFFFFFFu;
+	P.pe = (P.ecnt <= 64 && lane < P.ecnt) ? R.pos[Ea + lane] : 0xFFFFFFFFu;
+	return P;
+}
+
+// The deltas of the wave's values [L0, L1) are in src (LDS staging: src[l - L0]; or, GLOBAL, the place of
+// the read's one-byte stream: src[l]): write the samples they and their exceptions make.
+template <bool GLOBAL>
+__device__ __forceinline__ void emit_samples(const uint8_t *src, const EmitRead &R, const EmitPlan &P, uint32_t lane)
+{
+	const uint32_t L0 = P.L0, L1 = P.L1, Ea = P.Ea, ecnt = P.ecnt, Ia = P.Ia, Ib = P.Ib, pe = P.pe;
+	uint32_t base = P.base;
 	auto ex_below = [&](uint32_t key) -> uint32_t { // exceptions of the wave with pos < key
 		if (ecnt == 0)
 			return 0u;
@@ -895,29 +913,36 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 	for (uint32_t k0 = 2 * blockIdx.x; k0 < ntiles; k0 += 2 * gridDim.x, par ^= 1u) {
 		const uint32_t k = k0 + grp;
 		const bool has = k < ntiles; // (an odd tile count leaves the last group idle: it only keeps the barrier)
-		const HufTile *dp = a.htiles + (has ? k : k0);
-		const HufTRec *tr = a.htrec + (has ? k : k0);
-		const uint32_t nbits_t = has ? uniform(dp->nbits) : 0u;
-		const uint32_t want = uniform(dp->want);
-		const uint8_t *src = a.in + dp->src;
-		const uint64_t roff = dp->low; // the read's slot: samples in a.sig, one-byte values in a.low, exceptions
-		uint8_t *low = a.low + roff;
-		col_load<NDW>(col, src, (int32_t) tid * (OWN / 8), 0, (int32_t) ((nbits_t + 7) >> 3));
+		// the tile's two records in four loads issued together, then (their `read`) the read's: two memory round
+		// trips for everything the tile needs - field by field they were a dozen, each waited for
+		const uint4 *tp = reinterpret_cast<const uint4 *>(a.htiles + (has ? k : k0));
+		const uint4 *rp = reinterpret_cast<const uint4 *>(a.htrec + (has ? k : k0));
+		const uint4 t0 = tp[0], t1 = tp[1], r0 = rp[0], r1 = rp[1];
 		const uint32_t rec = has ? a.hrec[(uint64_t) k * HT + tid] : R_END;
+		static_assert(sizeof(HufTile) == 32 && sizeof(HufTRec) == 32 && sizeof(ReadMeta) == 32, "records are two 16-byte loads");
+		const uint4 *mp = reinterpret_cast<const uint4 *>(a.meta + uniform(t1.z)); // HufTile::read
+		const uint4 m0 = mp[0], m1 = mp[1];
+		const uint32_t nbits_t = has ? uniform(t1.x) : 0u;                            // HufTile::nbits
+		const uint32_t want = uniform(t1.w);                                          // ::want
+		const uint8_t *src = a.in + (((uint64_t) uniform(t0.y) << 32) | uniform(t0.x)); // ::src
+		const uint64_t roff = ((uint64_t) uniform(t0.w) << 32) | uniform(t0.z);       // ::low: the read's slot - samples
+		uint8_t *low = a.low + roff;                                                  // in a.sig, one-byte values in a.low, exceptions
+		col_load<NDW>(col, src, (int32_t) tid * (OWN / 8), 0, (int32_t) ((nbits_t + 7) >> 3));
 		const uint32_t cnt = rec >> 8;
 		const uint32_t inc = wave_scan(cnt);
 		if (lane == 63)
 			wtot[par][wv] = inc;
 		__syncthreads(); // the wave totals (and, the first time, the tables); columns and staging are private
-		uint64_t obase = has ? uniform(tr->base) : 0u; // codes of the read in front of this wave
-		uint32_t B0 = uniform(tr->dbase);              // ... and the sum of their deltas
+		uint64_t obase = has ? uniform(r0.z) : 0u; // HufTRec::base: codes of the read in front of this wave
+		uint32_t B0 = uniform(r0.w);               // ::dbase: ... and the sum of their deltas
+		const uint32_t wd[4] = { uniform(r1.x) & 0xFFFFu, uniform(r1.x) >> 16, uniform(r1.y) & 0xFFFFu, uniform(r1.y) >> 16 }; // ::wd
 #pragma unroll
 		for (int w2 = 0; w2 < HT / 64; w2++)
 			if (w2 < (int) (tid >> 6)) {
 				obase += uniform(wtot[par][grp * (HT / 64) + w2]);
-				B0 += uniform((uint32_t) tr->wd[w2]);
+				B0 += wd[w2];
 			}
-		const bool fused = has && uniform(tr->fused) != 0;
+		const bool fused = has && uniform(r1.w) != 0; // ::fused
 		const uint32_t wsum = uniform((uint32_t) __shfl((int) inc, 63, 64));
 		// the wave delivers values [obase, obase + wsum) of the read, cut at `want`
 		const uint32_t quota = obase >= want ? 0u : (wsum < want - (uint32_t) obase ? wsum : want - (uint32_t) obase);
@@ -928,23 +953,24 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 		uint8_t *dst = low + obase;
 		EmitRead R = {};
 		if (fused) {
-			const ReadMeta *m = a.meta + uniform(dp->read);
 			R.pos = a.ex_pos + roff;
 			R.val = a.ex_val + roff;
 			R.out = a.sig + roff;
-			R.nex = uniform(m->nex);
-			R.zd0 = uniform(m->zd0);
-			R.q = uniform(m->q);
-			R.nlow = uniform(m->nlow);
+			R.nex = uniform(m0.x);  // ReadMeta::nex
+			R.zd0 = uniform(m0.z);  // ::zd0
+			R.q = uniform(m0.w);    // ::q
+			R.nlow = uniform(m1.z); // ::nlow
 		}
 		// symbols go to the wave's staging buffer in their final order; a wave that holds more codes than
 		// the buffer takes (cannot happen with 5.4-bit codes on average) stores them byte by byte instead
+		// (the read's first exceptions: asked for now, needed behind the decode loop)
+		const uint32_t key = (fused && quota && lane < R.nex) ? R.pos[lane] - lane : 0xFFFFFFFFu;
 		if (wsum <= EMIT_STG) {
 			emit_codes(col, lut, lut2, a.huff, p0, nmine, stg + ex);
 			wave_lds_sync();
 			if (fused) {
 				if (quota)
-					emit_samples<false>(stg, R, (uint32_t) obase, quota, B0, lane);
+					emit_samples<false>(stg, R, emit_plan(R, (uint32_t) obase, quota, B0, lane, key), lane);
 			} else {
 				// the one-byte stream, for k_low_decode_chunked: 16-byte stores
 				for (uint32_t o = lane * 16; o < quota; o += 64 * 16) {
@@ -965,7 +991,7 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 			if (fused && quota) {
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the wave reads back what its lanes wrote
 				__builtin_amdgcn_wave_barrier();
-				emit_samples<true>(low, R, (uint32_t) obase, quota, B0, lane);
+				emit_samples<true>(low, R, emit_plan(R, (uint32_t) obase, quota, B0, lane, key), lane);
 			} else if (!fused) {
 				for (uint32_t b = 0; b < nmine; b++) { // deltas -> one-byte values, in place
 					const uint32_t dl = dst[ex + b];
