@@ -377,6 +377,14 @@ __device__ __forceinline__ uint32_t sync_tile(const DecodeArgs &a, uint32_t k, b
 		r.fused = 0;
 		a.htrec[k] = r;
 	}
+	if (tid < HT / 64 && has) { // what the waves in front of wave `tid` hold: k_huf_emit's waves start from here on their own
+		uint32_t cb = 0, db = 0;
+		for (uint32_t w2 = 0; w2 < tid; w2++) {
+			cb += T.wtot[w2];
+			db += T.wdt[w2];
+		}
+		a.hwave[(uint64_t) k * (HT / 64) + tid] = cb | (db << 16);
+	}
 	__syncthreads(); // the columns and lists are free again
 	return se;
 }
@@ -885,7 +893,6 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 	__shared__ uint32_t img[WGE / 64][NCOL * 64];
 	__shared__ uint32_t pad_row[64];
 	__shared__ __attribute__((aligned(16))) EmitStg stg_all;
-	__shared__ uint32_t wtot[2][WGE / 64];
 
 	const uint32_t grp = threadIdx.x >> 8;
 	const uint32_t tid = threadIdx.x & 255u;
@@ -908,17 +915,21 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 	}
 	uint32_t *col = img[wv] + lane;
 	uint8_t *stg = stg_all.s[wv];
-	uint32_t par = 0;
+	__syncthreads(); // the tables; from here on every wave is on its own: columns and staging are private, and
+	                 // what the other waves of its tile hold in front of it comes with the tile's records
 	// persistent workgroups: the tables are loaded once
-	for (uint32_t k0 = 2 * blockIdx.x; k0 < ntiles; k0 += 2 * gridDim.x, par ^= 1u) {
+	for (uint32_t k0 = 2 * blockIdx.x; k0 < ntiles; k0 += 2 * gridDim.x) {
 		const uint32_t k = k0 + grp;
-		const bool has = k < ntiles; // (an odd tile count leaves the last group idle: it only keeps the barrier)
+		const bool has = k < ntiles; // (an odd tile count leaves the last group idle)
+		if (!has)
+			break;
 		// the tile's two records in four loads issued together, then (their `read`) the read's: two memory round
 		// trips for everything the tile needs - field by field they were a dozen, each waited for
 		const uint4 *tp = reinterpret_cast<const uint4 *>(a.htiles + (has ? k : k0));
 		const uint4 *rp = reinterpret_cast<const uint4 *>(a.htrec + (has ? k : k0));
 		const uint4 t0 = tp[0], t1 = tp[1], r0 = rp[0], r1 = rp[1];
 		const uint32_t rec = has ? a.hrec[(uint64_t) k * HT + tid] : R_END;
+		const uint32_t hw = a.hwave[(uint64_t) k * (HT / 64) + (tid >> 6)];
 		static_assert(sizeof(HufTile) == 32 && sizeof(HufTRec) == 32 && sizeof(ReadMeta) == 32, "records are two 16-byte loads");
 		const uint4 *mp = reinterpret_cast<const uint4 *>(a.meta + uniform(t1.z)); // HufTile::read
 		const uint4 m0 = mp[0], m1 = mp[1];
@@ -930,18 +941,10 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 		col_load<NDW>(col, src, (int32_t) tid * (OWN / 8), 0, (int32_t) ((nbits_t + 7) >> 3));
 		const uint32_t cnt = rec >> 8;
 		const uint32_t inc = wave_scan(cnt);
-		if (lane == 63)
-			wtot[par][wv] = inc;
-		__syncthreads(); // the wave totals (and, the first time, the tables); columns and staging are private
-		uint64_t obase = has ? uniform(r0.z) : 0u; // HufTRec::base: codes of the read in front of this wave
-		uint32_t B0 = uniform(r0.w);               // ::dbase: ... and the sum of their deltas
-		const uint32_t wd[4] = { uniform(r1.x) & 0xFFFFu, uniform(r1.x) >> 16, uniform(r1.y) & 0xFFFFu, uniform(r1.y) >> 16 }; // ::wd
-#pragma unroll
-		for (int w2 = 0; w2 < HT / 64; w2++)
-			if (w2 < (int) (tid >> 6)) {
-				obase += uniform(wtot[par][grp * (HT / 64) + w2]);
-				B0 += wd[w2];
-			}
+		// HufTRec::base, ::dbase: codes of the read in front of the tile and the sum of their deltas; hwave: the same
+		// of the tile's waves in front of this one
+		const uint64_t obase = (uint64_t) uniform(r0.z) + (uniform(hw) & 0xFFFFu);
+		const uint32_t B0 = uniform(r0.w) + (uniform(hw) >> 16);
 		const bool fused = has && uniform(r1.w) != 0; // ::fused
 		const uint32_t wsum = uniform((uint32_t) __shfl((int) inc, 63, 64));
 		// the wave delivers values [obase, obase + wsum) of the read, cut at `want`

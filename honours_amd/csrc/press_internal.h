@@ -170,6 +170,7 @@ struct DecodeArgs {
 	uint32_t *hrec;           // [max_htiles * HUF_HT] one record per subsequence: start | codes << 8
 	uint32_t *hlist;          // [2 * hlist_cap] tiles of a repair round: {tile, true start}
 	uint32_t *hread;          // [2 * nreads] first tile, number of tiles of read r
+	uint32_t *hwave;          // [max_htiles * 4] per wave of a tile: codes | sum of their deltas << 16 of the tile's waves in front of it
 	uint32_t max_htiles;
 	uint32_t hlist_cap;
 	uint32_t huf_minlen;      // shortest code of the table (selects the subsequence size on the host)
