@@ -25,7 +25,7 @@ STORE8 = ("k_svb_encode_chunked", "k_low_encode_chunked")
 PRESS = ("k_chunk_prep<", "k_svb_encode", "k_ex_scan", "k_ex_prefix", "k_ex_list", "k_ex_section", "k_ex_fill",
          "k_low_encode", "k_huff_encode", "k_ex_redo", "k_zs_layout", "k_zs_blocks", "k_zs_blockmap", "k_zs_hist",
          "k_zs_keycount", "k_zs_table", "k_zs_keylist", "k_zs_bits", "k_zs_plan", "k_zs_encode", "k_zs_rawframes",
-         "k_rcs_encode", "k_rcc_encode")
+         "k_rcs_encode", "k_rcc_encode", "k_rcm_encode")
 
 
 def run_pass(method, counter, tag):
