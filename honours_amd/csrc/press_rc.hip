@@ -254,7 +254,8 @@ __global__ __launch_bounds__(64) void k_rcs_decode(DecodeArgs a)
 // LDS, reads handed out by a ticket to as many workgroups as there are CUs.  Every lane runs the same
 // interval arithmetic (uniform values); encoding, the eight predictors of a byte - their contexts are
 // known in advance - are fetched and updated by eight lanes at once, so the dependent chain is
-// arithmetic only; decoding, both candidates for the next context are fetched while a bit is decided.
+// arithmetic only; decoding, the wave fetches the whole row in front of a byte (four predictors per lane) and
+// the eight dependent steps pick theirs with v_readlane (the interval arithmetic runs on the scalar unit).
 // What the format leaves: 256 reads in flight on the chip, each at one byte per few hundred cycles.
 
 namespace {
@@ -410,46 +411,48 @@ __global__ __launch_bounds__(RCC_WG) void k_rcc_decode(DecodeArgs a)
 			return w;
 		};
 		uint32_t wn = get32(); // the next word is always in flight before it is needed
+		// (readfirstlane: every lane holds the same word - said so, the interval arithmetic runs on the scalar unit)
 		auto next32 = [&]() -> uint32_t {
-			const uint32_t w = wn;
+			const uint32_t w = (uint32_t) __builtin_amdgcn_readfirstlane((int) wn);
 			wn = get32();
 			return w;
 		};
 		code = next32();
 		code = (code << 32) | next32();
-		const uint16_t *row = mb;
+		uint16_t *row = mb;
 		uint32_t acc = 0; // four decoded bytes
 		for (uint64_t i = 0; i < n; i++) {
+			// nothing but the eight nodes on a byte's path changes while it is decoded: the whole row (255
+			// probabilities, four per lane in one 8-byte LDS read) is fetched in front of the byte and the
+			// eight dependent steps pick theirs with v_readlane - no memory access on the chain
+			uint2 pq;
+			__builtin_memcpy(&pq, __builtin_assume_aligned(row + 4u * lane, 8), 8);
 			uint32_t x = 1;
-			uint32_t p = row[1];
 #pragma unroll
 			for (int k = 7; k >= 0; k--) {
-				// both candidates for the next context while this bit is being decided
-				uint32_t c0 = 0, c1 = 0;
-				if (k) {
-					c0 = row[2 * x];
-					c1 = row[2 * x + 1];
-				}
+				const int sl = __builtin_amdgcn_readfirstlane((int) (x >> 2));
+				const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) pq.x, sl);
+				const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) pq.y, sl);
+				const uint32_t pair = (x & 2u) ? hi : lo;
+				const uint32_t p = (x & 1u) ? pair >> 16 : pair & 0xFFFFu;
 				if ((k & 1) && range < RC_TOP) {
 					range <<= 32;
 					code = (code << 32) | next32();
 				}
 				const uint64_t t = (range >> 15) * p;
-				uint16_t *slot = const_cast<uint16_t *>(row) + x;
 				if (code < t) {
 					range = t;
-					if (lane == 0)
-						*slot = (uint16_t) (p + (32768u - p + 31u) / 32u - 1u);
 					x = 2 * x + 1;
-					p = c1;
 				} else {
 					range -= t;
 					code -= t;
-					if (lane == 0)
-						*slot = (uint16_t) (p - (p >> 5));
 					x = 2 * x;
-					p = c0;
 				}
+			}
+			if (lane < 8) { // the eight nodes of the path move towards their bits (as in the encoder)
+				const uint32_t node = x >> (lane + 1u), bit = (x >> lane) & 1u;
+				const uint32_t pk = row[node];
+				row[node] = (uint16_t) (bit ? pk + (32768u - pk + 31u) / 32u - 1u : pk - (pk >> 5));
 			}
 			acc |= (x & 0xFFu) << (8 * ((uint32_t) i & 3u));
 			if (((uint32_t) i & 3u) == 3u || i + 1 == n) {
@@ -478,8 +481,10 @@ __global__ __launch_bounds__(RCC_WG) void k_rcc_decode(DecodeArgs a)
 // State per read: 256 + 256 x 256 predictors and 256 x 17 curve points = 137 KiB: ONE READ PER WORKGROUP
 // like the order-1 coder above, everything in LDS.  Encoding, the eight nodes of a byte are known in
 // advance and distinct (so are their curves): eight lanes fetch, mix and update them side by side and the
-// dependent chain is the interval arithmetic alone.  Decoding, the predictions of both children of a node
-// are fetched while its bit is decided; the curve's points are one more LDS round trip per bit.
+// dependent chain is the interval arithmetic alone.  Decoding, the wave mixes the probabilities of ALL 255
+// nodes in front of every byte (four nodes per lane) and the eight dependent steps pick theirs with a
+// v_readlane: no memory access on the chain either (first version, one LDS round trip per bit for the
+// curve: 9.9 s for the 8192-read batch).
 // (restated from its behaviour, pinned against the compiled reference by oracle/press_oracle.c:
 // po_rcms_encode / po_rcms_decode and tests/test_oracle_golden.py)
 
@@ -666,8 +671,9 @@ __global__ __launch_bounds__(RCC_WG) void k_rcm_decode(DecodeArgs a)
 			return w;
 		};
 		uint32_t wn = get32(); // the next word is always in flight before it is needed
+		// (readfirstlane: every lane holds the same word - said so, the interval arithmetic runs on the scalar unit)
 		auto next32 = [&]() -> uint32_t {
-			const uint32_t w = wn;
+			const uint32_t w = (uint32_t) __builtin_amdgcn_readfirstlane((int) wn);
 			wn = get32();
 			return w;
 		};
@@ -676,25 +682,37 @@ __global__ __launch_bounds__(RCC_WG) void k_rcm_decode(DecodeArgs a)
 		uint16_t *row = L.mb1;
 		uint32_t acc = 0; // four decoded bytes
 		for (uint64_t i = 0; i < n; i++) {
+			// The nodes on a byte's path are distinct and nothing else changes while the byte is decoded: the
+			// probabilities of ALL 255 nodes are known in front of it.  Lane l takes nodes l, l + 64, l + 128,
+			// l + 192 (two LDS round trips for the lot), and the eight dependent steps fetch theirs with a
+			// v_readlane - no memory access on the chain.
+			uint32_t pm[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const uint32_t node = lane + 64u * j;
+				const uint32_t q0 = L.mb0[node], q1 = row[node];
+				const uint32_t p = (q0 + 15u * q1) >> 4;
+				const uint16_t *cell = &L.sse[node][p >> 12];
+				pm[j] = rcm_mix(p, cell[0], cell[1]);
+			}
 			uint32_t x = 1;
-			uint32_t p0 = L.mb0[1], p1 = row[1];
 #pragma unroll
 			for (int k = 7; k >= 0; k--) {
-				// the predictions of both children while this bit is being decided (a pair of neighbours each)
-				uint32_t c0 = 0, c1 = 0;
-				if (k) { // (memcpy: these words alias the 16-bit stores of the updates)
-					__builtin_memcpy(&c0, __builtin_assume_aligned(L.mb0 + 2 * x, 4), 4);
-					__builtin_memcpy(&c1, __builtin_assume_aligned(row + 2 * x, 4), 4);
-				}
-				const uint32_t p = (p0 + 15u * p1) >> 4;
-				uint16_t *cell = &L.sse[x][p >> 12];
-				const uint32_t x1 = cell[0], x2 = cell[1];
-				const uint32_t pm = rcm_mix(p, x1, x2);
+				// depth 7 - k: nodes 2^(7-k) .. 2^(8-k) - 1
+				const int sl = __builtin_amdgcn_readfirstlane((int) (x & 63u));
+				uint32_t pk;
+				if (k >= 2)
+					pk = (uint32_t) __builtin_amdgcn_readlane((int) pm[0], sl);
+				else if (k == 1)
+					pk = (uint32_t) __builtin_amdgcn_readlane((int) pm[1], sl);
+				else
+					pk = (x & 64u) ? (uint32_t) __builtin_amdgcn_readlane((int) pm[3], sl)
+						       : (uint32_t) __builtin_amdgcn_readlane((int) pm[2], sl);
 				if (range < RC_TOP) {
 					range <<= 32;
 					code = (code << 32) | next32();
 				}
-				const uint64_t t = (range >> 16) * pm;
+				const uint64_t t = (range >> 16) * pk;
 				const uint32_t bit = code < t ? 1u : 0u;
 				if (bit) {
 					range = t;
@@ -702,15 +720,19 @@ __global__ __launch_bounds__(RCC_WG) void k_rcm_decode(DecodeArgs a)
 					range -= t;
 					code -= t;
 				}
-				if (lane == 0) {
-					L.mb0[x] = (uint16_t) rcm_step(p0, 2, bit);
-					row[x] = (uint16_t) rcm_step(p1, 4, bit);
-					cell[0] = (uint16_t) rcm_step(x1, 6, bit);
-					cell[1] = (uint16_t) rcm_step(x2, 6, bit);
-				}
 				x = 2 * x + bit;
-				p0 = bit ? c0 >> 16 : c0 & 0xFFFFu;
-				p1 = bit ? c1 >> 16 : c1 & 0xFFFFu;
+			}
+			if (lane < 8) { // the eight nodes of the path move towards their bits (as in the encoder)
+				const uint32_t xx = x; // 0x100 | byte
+				const uint32_t node = xx >> (lane + 1u), bit = (xx >> lane) & 1u;
+				const uint32_t q0 = L.mb0[node], q1 = row[node];
+				const uint32_t p = (q0 + 15u * q1) >> 4;
+				uint16_t *cell = &L.sse[node][p >> 12];
+				const uint32_t x1 = cell[0], x2 = cell[1];
+				L.mb0[node] = (uint16_t) rcm_step(q0, 2, bit);
+				row[node] = (uint16_t) rcm_step(q1, 4, bit);
+				cell[0] = (uint16_t) rcm_step(x1, 6, bit);
+				cell[1] = (uint16_t) rcm_step(x2, 6, bit);
 			}
 			acc |= (x & 0xFFu) << (8 * ((uint32_t) i & 3u));
 			if (((uint32_t) i & 3u) == 3u || i + 1 == n) {
