@@ -1231,7 +1231,9 @@ __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 // exceptions in front of every chunk (one thread per read); the read's total and its ex-zd shift
 __global__ __launch_bounds__(256) void k_ex_prefix(BatchArgs a, int exzd)
 {
-	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	// one wave per read (a thread per read walked the 175 chunks of the longest read one after the other)
+	const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63;
 	if (r >= a.nreads)
 		return;
 	const uint32_t n = a.nsamp[r];
@@ -1240,27 +1242,40 @@ __global__ __launch_bounds__(256) void k_ex_prefix(BatchArgs a, int exzd)
 	ReadMeta *m = a.meta + r;
 	ChunkDesc *dp = a.chunks + a.first_chunk[r];
 	const uint32_t nch = (n + CHUNK - 1) / CHUNK;
-	uint64_t e = 0;
-	for (uint32_t j = 0; j < nch; j++) {
-		dp[j].ebefore = e;
-		e += (uint64_t) dp[j].ecnt[0] + dp[j].ecnt[1] + dp[j].ecnt[2] + dp[j].ecnt[3];
-	}
-	m->nex = (uint32_t) e;
+	// exclusive prefix of a 64-bit count over the chunks, 64 at a time; returns the total
+	auto scan = [&](auto count_of, auto store) -> uint64_t {
+		uint64_t carry = 0;
+		for (uint32_t j0 = 0; j0 < nch; j0 += 64) {
+			const uint32_t j = j0 + lane;
+			const uint64_t c = j < nch ? count_of(j) : 0ull;
+			// (two 32-bit scans, of the counts' low 20 bits and of the rest: neither can overflow over 64 chunks)
+			const uint32_t lo = wave_incl_scan_dpp((uint32_t) (c & 0xFFFFFu)), hi = wave_incl_scan_dpp((uint32_t) (c >> 20));
+			const uint64_t inc = (uint64_t) lo + ((uint64_t) hi << 20);
+			if (j < nch)
+				store(j, carry + inc - c);
+			const uint64_t tot = (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) lo, 63) +
+					     ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) hi, 63) << 20);
+			carry += tot;
+		}
+		return carry;
+	};
+	const uint64_t e = scan([&](uint32_t j) { return (uint64_t) dp[j].ecnt[0] + dp[j].ecnt[1] + dp[j].ecnt[2] + dp[j].ecnt[3]; },
+				[&](uint32_t j, uint64_t v) { dp[j].ebefore = v; });
 	if (a.cbits) { // Huffman code bits in front of every chunk
 		ChunkBits *cb = a.cbits + a.first_chunk[r];
-		uint64_t b = 0;
-		for (uint32_t j = 0; j < nch; j++) {
-			cb[j].before = b;
-			b += (uint64_t) cb[j].q[0] + cb[j].q[1] + cb[j].q[2] + cb[j].q[3];
+		(void) scan([&](uint32_t j) { return (uint64_t) cb[j].q[0] + cb[j].q[1] + cb[j].q[2] + cb[j].q[3]; },
+			    [&](uint32_t j, uint64_t v) { cb[j].before = v; });
+	}
+	if (lane == 0) {
+		m->nex = (uint32_t) e;
+		uint32_t q = 0;
+		if (exzd) { // ex_zd.c:358-381
+			const uint32_t ored = m->ored;
+			while (q < 5 && !((ored >> q) & 1u))
+				q++;
 		}
+		m->q = q;
 	}
-	uint32_t q = 0;
-	if (exzd) { // ex_zd.c:358-381
-		const uint32_t ored = m->ored;
-		while (q < 5 && !((ored >> q) & 1u))
-			q++;
-	}
-	m->q = q;
 }
 
 // the exception list (position, value) at its final rank: only the flagged sub-tiles are read again
@@ -1971,7 +1986,7 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, int ent, hipStream_t 
 		hipLaunchKernelGGL(k_ex_redo_flag, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a);
 		hipLaunchKernelGGL((k_ex_scan_chunked<true>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	}
-	hipLaunchKernelGGL(k_ex_prefix, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a, fmt == EXF_EXZD ? 1 : 0);
+	hipLaunchKernelGGL(k_ex_prefix, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, fmt == EXF_EXZD ? 1 : 0);
 	hipLaunchKernelGGL(k_ex_list, dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	launch_ex_section(a, fmt, ent, s);
 	if (ent >= 2) { // range coder: the one-byte values go to a temporary, one lane (order 1: one workgroup) per read codes them
