@@ -316,6 +316,8 @@ def main():
                 rec["steps"], rec["warmup"] = args.steps, args.warmup
                 if not args.no_cpu:
                     rec["cpu_baseline"] = cpu_baseline(mm, b, budget_s=6.0)
+                if mm == "zstd_svb_zd":
+                    rec["libzstd_frames"] = libzstd_frames(torch, press, b, args.steps)
                 line["configs"][key] = rec
             line["e2e_host"] = e2e_host(torch, press, b, m)
             del b
@@ -328,6 +330,72 @@ def main():
 
     if world > 1:
         dist.destroy_process_group()
+
+
+def libzstd_frames(torch, press, b, steps, nreads=1024):
+    """Config 3 the other way round: the REFERENCE's VBZ streams - ZSTD_compress level 1 of [u32 n][svb-zd]
+    (press.c:1860, press.h:275), made here by the host's libzstd from the device's own svb-zd streams - read
+    by the device (sequences, FSE tables, match copies: k_zs_exec).  `zstd_host_frames` = frames the device
+    handed to libzstd on the host (0 = none).  None if this host has no libzstd."""
+    import ctypes
+    import struct
+
+    z = None
+    for name in ("/opt/conda/lib/libzstd.so.1", "libzstd.so.1", "libzstd.so"):
+        try:
+            z = ctypes.CDLL(name)
+            break
+        except OSError:
+            continue
+    if z is None:
+        return None
+    z.ZSTD_compress.restype = ctypes.c_size_t
+    z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    z.ZSTD_isError.argtypes = [ctypes.c_size_t]
+    k = min(nreads, b.R)
+    n = b.n[:k]
+    d_off, d_n = b.d_off[:k].contiguous(), b.d_n[:k].contiguous()
+    caps = (np.array([press.bound("svb_zd", int(x)) for x in n], dtype=np.int64) + 64 + 127) // 128 * 128
+    out_off = np.concatenate([[0], np.cumsum(caps)])
+    d_out = torch.empty(int(out_off[-1]) + 64, dtype=torch.uint8, device=b.dev)
+    d_out_off = torch.from_numpy(out_off).to(b.dev)
+    d_len = torch.zeros(k, dtype=torch.int64, device=b.dev)
+    press.press_batch("svb_zd", b.sig, d_off, d_n, d_out, d_out_off, d_len)
+    torch.cuda.synchronize()
+    host, lens = d_out.cpu().numpy(), d_len.cpu().numpy()
+    frames = []
+    for r in range(k):
+        inner = struct.pack("<I", int(n[r])) + host[int(out_off[r]): int(out_off[r]) + int(lens[r])].tobytes()
+        src = np.frombuffer(inner, dtype=np.uint8)
+        dst = np.empty(len(inner) + len(inner) // 100 + 1024, dtype=np.uint8)
+        c = z.ZSTD_compress(dst.ctypes.data, dst.size, src.ctypes.data, len(inner), 1)
+        assert not z.ZSTD_isError(c)
+        frames.append(dst[:c].tobytes())
+    flen = np.array([len(f) for f in frames], dtype=np.int64)
+    foff = np.concatenate([[0], np.cumsum((flen + 63) // 64 * 64)])
+    arena = np.zeros(int(foff[-1]) + 64, dtype=np.uint8)
+    for r, f in enumerate(frames):
+        arena[int(foff[r]): int(foff[r]) + len(f)] = np.frombuffer(f, dtype=np.uint8)
+    d_in = torch.from_numpy(arena).to(b.dev)
+    d_in_off = torch.from_numpy(foff[:-1].copy()).to(b.dev)
+    d_in_len = torch.from_numpy(flen).to(b.dev)
+    d_outn = torch.zeros(k, dtype=torch.int32, device=b.dev)
+    b.d_back.zero_()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for it in range(1 + steps):  # the first pass warms up
+        if it == 1:
+            ev[0].record()
+        press.depress_batch("zstd_svb_zd", d_in, d_in_off, d_in_len, b.d_back, d_off, d_n, d_outn)
+    ev[1].record()
+    torch.cuda.synchronize()
+    nsamp = int(b.starts[k])
+    assert torch.equal(b.d_back[:nsamp], b.sig[:nsamp]), "libzstd frames: not lossless"
+    ms = ev[0].elapsed_time(ev[1]) / steps
+    raw = 2 * int(n.sum())
+    return {"what": "depress_batch(zstd_svb_zd) of ZSTD_compress level-1 frames (the reference's own VBZ streams), "
+                    "device resident", "reads": k, "raw_bytes": raw, "ratio": round(raw / float(flen.sum()), 6),
+            "depress_ms": round(ms, 4), "depress_MBps": round(raw / (ms * 1e-3) / 1e6, 1),
+            "zstd_host_frames": int(press.load_library().press_hip_zstd_host_frames())}
 
 
 def e2e_host(torch, press, b, m, nreads=2048):
