@@ -3,11 +3,11 @@
 // The stream has no synchronisation points, but Huffman codes self-synchronise: a decoder
 // started at a wrong bit position falls back onto true code boundaries after a few codes.
 // The payload of every read is cut into SUBSEQUENCES of OWN bits (256 for the NA12878 table,
-// whose shortest code has 4 bits), one lane each; a TILE = 256 subsequences (8 KiB) = one
-// 256-thread workgroup at a time.  Nothing in the two heavy kernels waits for another tile:
+// whose shortest code has 4 bits), one lane each; a TILE = 256 subsequences (8 KiB), two of them side by
+// side in a 512-thread workgroup that shares the tables.  Nothing in the two heavy kernels waits for another tile:
 //
-//   k_huf_sync   where do codes start?  Lengths only: one LDS look-up takes every whole code that fits
-//                in 12 bits.  Lane i runs through the RU = OWN/2 bits in front of its subsequence from
+//   k_huf_sync   where do codes start?  Lengths (and the sample deltas the symbols stand for - no symbols): one
+//                LDS look-up takes every whole code that fits in 12 bits.  Lane i runs through the RU = OWN/2 bits in front of its subsequence from
 //                their first bit: where that run crosses into its own subsequence is its guess of the
 //                first code's start (right in ~97 % of the cases); then through its own subsequence.
 //                Lanes whose guess is not where the left neighbour ended are decoded again from there -
@@ -27,7 +27,8 @@
 //                never synchronises - the rounds before it are only faster); then the codes in front
 //                of every tile and what the read delivers.
 //   k_huf_emit   lane i decodes its subsequence once more from its true start, now with the two-symbol
-//                table, into the wave's LDS staging buffer at its final order (scan of the counts).
+//                table, into the wave's LDS staging buffer at its final order (scan of the counts); the
+//                count k_huf_sync found ends the loop.  Every wave is on its own (no barrier in the loop).
 //                The one-byte values do not leave the chip: k_huf_sync also summed the sample deltas they
 //                stand for (per wave and tile, from the same look-up), k_huf_chain made those the sample
 //                value in front of every tile, so the wave turns its staging buffer into samples itself
