@@ -526,6 +526,29 @@ def test_huffman_sample_writer_paths(oracle):
         assert bk is not None and np.array_equal(bk, sgl)
 
 
+def test_huffman_batch_mixes_both_decode_ways(oracle):
+    """one depress batch in which some reads take k_huf_emit's own sample writer and others (streams cut short:
+    their exceptions no longer interleave with what the payload delivers) the two-step way through
+    k_low_decode_chunked - every read as the oracle decodes it"""
+    m = "shuffman_vbe21_zd"
+    sig, off = synth.synth_batch(33, 0, 6)
+    reads = [sig[int(off[i]):int(off[i + 1])][:120000] for i in range(6)]
+    streams, ns = [], []
+    for i, r in enumerate(reads):
+        ret, full = oracle.press(m, r)
+        assert ret == 0
+        if i % 2:  # cut inside the payload: fewer values than the header announces
+            full = full[:len(full) - (len(full) // (3 + i))]
+        streams.append(full)
+        ns.append(len(r))
+    backs = press.depress_batch_host(m, streams, ns)
+    for st, n, bk in zip(streams, ns, backs):
+        ro, bo = oracle.depress(m, st, n)
+        assert (bk is not None) == (ro == 0), (n, ro)
+        if ro == 0:
+            assert bk.size == bo.size and np.array_equal(bk, bo), (n, bk.size, bo.size)
+
+
 def test_longest_read_in_a_mixed_batch(oracle):
     """a read of NA12878's maximum length (5.7 M samples: 175 chunks, ~420 Huffman tiles - deep
     look-back chains) next to tiny reads in ONE batch call, byte parity with the oracle for the
