@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 name=$1; shift 2
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$name -- "$@" > gpurun_out/prof_$name.out 2> gpurun_out/prof_$name.err
+timeout -k 10 ${PROF_TIMEOUT:-600} rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$name -- "$@" > gpurun_out/prof_$name.out 2> gpurun_out/prof_$name.err
 f=$(ls gpurun_out/prof_$name/*/*kernel_stats.csv | head -1)
 cp "$f" gpurun_out/${name}_kernel_stats.csv
 python3 - "$f" <<'PY'
