@@ -821,7 +821,7 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 			if (i0 < n)
 				__builtin_memcpy(&dd, data + eb + i0, 8);
 		}
-		dat[k] = dd;
+		dat[k] = dd; // (k_low_decode_chunked's unconditional loads were tried here too: 82 instead of 51 VGPRs, 6 % slower)
 	}
 
 	// ---- phase 2: delta sums (16-bit wraparound) - per lane inside its sub-tile, per sub-tile
@@ -1783,17 +1783,18 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 	STAMP(2);
 
 	// ---- phase 1: one-byte values of the plain sub-tiles (8 per lane, any alignment)
+	const uint8_t *zeros8 = reinterpret_cast<const uint8_t *>(a.ctl->pad2); // (zeroed with the control block)
 	uint2 dat[CK];
 #pragma unroll
 	for (int k = 0; k < CK; k++) {
 		const uint32_t i0 = ws + k * SUB + lane * 8;
-		uint2 dd = make_uint2(0, 0);
-		if ((plain >> k) & 1u) {
-			const uint32_t eb = e_lo + uni(s_cnt[w][k]);
-			if (i0 < n)
-				__builtin_memcpy(&dd, low + (i0 - 1 - eb), 8);
-		}
-		dat[k] = dd;
+		// (every sub-tile loads, the ones that are not plain and the lanes behind the read's end zeros from the
+		// control block: with the load under a branch or a lane mask the compiler merges the zero and the loaded
+		// value in other registers right behind the load and waits for it - these sixteen loads went out one
+		// after the other)
+		const uint32_t eb = e_lo + uni(s_cnt[w][k]);
+		const uint8_t *src = (((plain >> k) & 1u) && i0 < n) ? low + (i0 - 1 - eb) : zeros8;
+		__builtin_memcpy(&dat[k], src, 8);
 	}
 
 	// ---- phase 2: delta sums
