@@ -526,6 +526,34 @@ def test_huffman_sample_writer_paths(oracle):
         assert bk is not None and np.array_equal(bk, sgl)
 
 
+@pytest.mark.parametrize("m", ["shuffman_vbe21_zd", "shuffman_vbbe21_zd", "shuffman_vbsse21_zd"])
+def test_huffman_batch_of_many_small_reads(oracle, m):
+    """four hundred reads of 2 .. 3000 samples (and a few of 40 000) in ONE batch: tiles of a handful of
+    subsequences, waves that deliver two values, exceptions at every density up to "every sample" - streams
+    equal to the oracle's, samples back exactly"""
+    rng = np.random.default_rng(77)
+    reads = []
+    for i in range(400):
+        n = int(rng.integers(2, 3001)) if i % 50 else 40000 + i
+        spread = int(rng.choice([1, 3, 20, 127]))
+        steps = rng.integers(-spread, spread + 1, size=n)
+        pex = float(rng.choice([0.0, 0.001, 0.05, 0.5, 1.0]))
+        steps[rng.random(n) < pex] += int(rng.choice([300, -300, 2000]))
+        r = np.cumsum(steps).astype(np.int16)
+        if shuff_ok(m, r):
+            reads.append(r)
+    caps = [int(press.bound(m, len(r))) + 8 * len(r) + 1024 for r in reads]  # (the reference's bound is too small
+    streams = press.press_batch_host(m, reads, caps=caps)                      # for exception-heavy reads, press.c:2575)
+    wants = []
+    for r, st, cap in zip(reads, streams, caps):
+        ret, want = oracle.press(m, r, cap=cap)
+        assert ret == 0 and st == want, (m, len(r), ret, st is None)
+        wants.append(want)
+    backs = press.depress_batch_host(m, wants, [len(r) for r in reads])
+    for r, bk in zip(reads, backs):
+        assert bk is not None and np.array_equal(bk, r), (m, len(r))
+
+
 def test_huffman_batch_mixes_both_decode_ways(oracle):
     """one depress batch in which some reads take k_huf_emit's own sample writer and others (streams cut short:
     their exceptions no longer interleave with what the payload delivers) the two-step way through
