@@ -1281,14 +1281,15 @@ __global__ __launch_bounds__(256) void k_ex_prefix(BatchArgs a, int exzd)
 // the exception list (position, value) at its final rank: only the flagged sub-tiles are read again
 __global__ __launch_bounds__(CWG) void k_ex_list(BatchArgs a)
 {
-	const uint32_t t = blockIdx.x;
+	// one WAVE per chunk (its four quarters one after the other: nearly all of them hold no exception) - a
+	// workgroup per chunk meant 150 000 waves that read a descriptor and left
+	const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (t >= uni(a.ctl->nchunks))
 		return;
 	const int lane = threadIdx.x & 63;
-	const int w = (int) uni(threadIdx.x >> 6);
 	const ChunkDesc *dp = a.chunks + t;
-	const uint32_t kmask = uni(dp->kmask[w]);
-	if (!kmask)
+	const uint32_t km[4] = { uni(dp->kmask[0]), uni(dp->kmask[1]), uni(dp->kmask[2]), uni(dp->kmask[3]) };
+	if (!(km[0] | km[1] | km[2] | km[3]))
 		return;
 	const ChunkU d = load_chunk(dp);
 	const uint32_t n = d.n;
@@ -1296,31 +1297,36 @@ __global__ __launch_bounds__(CWG) void k_ex_list(BatchArgs a)
 	const int16_t *in = a.sig + d.sig_off;
 	uint32_t *lpos = a.ex_pos + d.sig_off;
 	uint32_t *lval = a.ex_val + d.sig_off;
-	const uint32_t ws = d.j * CHUNK + w * WAVE_SAMPLES;
-	const uint32_t c0 = uni(dp->ecnt[0]), c1 = uni(dp->ecnt[1]), c2 = uni(dp->ecnt[2]);
-	uint32_t rank = (uint32_t) uni64(dp->ebefore) + (w > 0 ? c0 : 0u) + (w > 1 ? c1 : 0u) + (w > 2 ? c2 : 0u);
-	for (uint32_t mm = kmask; mm; mm &= mm - 1) {
-		const uint32_t k = (uint32_t) __builtin_ctz(mm);
-		const uint32_t sub0 = ws + k * SUB;
-		const uint32_t i0 = sub0 + lane * 8;
-		uint32_t carry = sub0 ? (uint32_t) (uint16_t) in[sub0 - 1] << 16 : 0u;
-		const uint4 z = sub_zd(sub_load(in, n, i0), n, i0, carry, q);
-		const uint32_t em = exc_mask(z, i0);
-		const uint32_t c = __popc(em);
-		const uint32_t inc = wave_incl_scan_dpp(c);
-		uint32_t p = rank + inc - c;
-		const uint32_t zz[4] = { z.x, z.y, z.z, z.w };
-		if (em) {
+	const uint32_t cnt[4] = { uni(dp->ecnt[0]), uni(dp->ecnt[1]), uni(dp->ecnt[2]), uni(dp->ecnt[3]) };
+	uint32_t rank = (uint32_t) uni64(dp->ebefore);
 #pragma unroll
-			for (int h = 0; h < 8; h++) {
-				if ((em >> h) & 1u) {
-					lpos[p] = i0 + h - 1;
-					lval[p] = (zz[h >> 1] >> (16 * (h & 1))) & 0xFFFFu;
-					p++;
+	for (int w = 0; w < 4; w++) {
+		const uint32_t ws = d.j * CHUNK + w * WAVE_SAMPLES;
+		uint32_t rk = rank;
+		for (uint32_t mm = km[w]; mm; mm &= mm - 1) {
+			const uint32_t k = (uint32_t) __builtin_ctz(mm);
+			const uint32_t sub0 = ws + k * SUB;
+			const uint32_t i0 = sub0 + lane * 8;
+			uint32_t carry = sub0 ? (uint32_t) (uint16_t) in[sub0 - 1] << 16 : 0u;
+			const uint4 z = sub_zd(sub_load(in, n, i0), n, i0, carry, q);
+			const uint32_t em = exc_mask(z, i0);
+			const uint32_t c = __popc(em);
+			const uint32_t inc = wave_incl_scan_dpp(c);
+			uint32_t p = rk + inc - c;
+			const uint32_t zz[4] = { z.x, z.y, z.z, z.w };
+			if (em) {
+#pragma unroll
+				for (int h = 0; h < 8; h++) {
+					if ((em >> h) & 1u) {
+						lpos[p] = i0 + h - 1;
+						lval[p] = (zz[h >> 1] >> (16 * (h & 1))) & 0xFFFFu;
+						p++;
+					}
 				}
 			}
+			rk += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
 		}
-		rank += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+		rank += cnt[w];
 	}
 }
 
@@ -1988,7 +1994,7 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, int ent, hipStream_t 
 		hipLaunchKernelGGL((k_ex_scan_chunked<true>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	}
 	hipLaunchKernelGGL(k_ex_prefix, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, fmt == EXF_EXZD ? 1 : 0);
-	hipLaunchKernelGGL(k_ex_list, dim3(a.max_chunks), dim3(CWG), 0, s, a);
+	hipLaunchKernelGGL(k_ex_list, dim3((a.max_chunks + 3) / 4), dim3(CWG), 0, s, a);
 	launch_ex_section(a, fmt, ent, s);
 	if (ent >= 2) { // range coder: the one-byte values go to a temporary, one lane (order 1: one workgroup) per read codes them
 		hipLaunchKernelGGL(k_low_encode_chunked, dim3(a.max_chunks), dim3(CWG), 0, s, a);
