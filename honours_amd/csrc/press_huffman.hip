@@ -21,7 +21,7 @@
 //                window over the column (the dword behind the window is fetched while the look-up is in
 //                flight); the last few codes take a careful loop.
 //   k_huf_tlinks tiles whose assumed start is not where the tile in front ended (3 %) are listed and
-//   k_huf_sync   done again from the true start (the same kernel over the list), twice.
+//   k_huf_sync   done again from the true start (the same kernel over the list).
 //   k_huf_chain  one workgroup per read: what is still broken is repaired serially, tile after tile
 //                (this alone is enough for ANY table and stream - a code whose lengths share a factor
 //                never synchronises - the rounds before it are only faster); then the codes in front
