@@ -1047,20 +1047,37 @@ __global__ __launch_bounds__(256) void k_huff_tiles(DecodeArgs a)
 		a.hread[2 * r] = base;
 		a.hread[2 * r + 1] = nt;
 	}
+	// the descriptors: the wave writes the tiles of its 64 reads together, 64 tiles at a time (a lane per read
+	// wrote the 420 tiles of the longest read one after the other)
+	uint64_t src0 = 0, low0 = 0, nbits = 0;
+	uint32_t want = 0;
 	if (nt) {
 		const ReadMeta *m = a.meta + r;
 		const uint32_t hdr = m->hdr + m->seclen + 4;
 		const uint64_t nbytes64 = a.in_len[r] - hdr;
-		const uint64_t nbits = 8ull * (nbytes64 > 0x1FFFFFFFull ? 0x1FFFFFFFull : nbytes64);
-		for (uint32_t t = 0; t < nt; t++) {
+		nbits = 8ull * (nbytes64 > 0x1FFFFFFFull ? 0x1FFFFFFFull : nbytes64);
+		src0 = a.in_off[r] + hdr;
+		low0 = a.off[r];
+		want = m->nlow;
+	}
+	unsigned long long todo = __ballot(nt != 0);
+	while (todo) {
+		const int rr = __builtin_ctzll(todo);
+		todo &= todo - 1;
+		const uint32_t r_nt = (uint32_t) __shfl((int) nt, rr, 64), r_base = (uint32_t) __shfl((int) base, rr, 64);
+		const uint32_t r_read = (uint32_t) __shfl((int) r, rr, 64), r_want = (uint32_t) __shfl((int) want, rr, 64);
+		const uint64_t r_src = ((uint64_t) (uint32_t) __shfl((int) (src0 >> 32), rr, 64) << 32) | (uint32_t) __shfl((int) src0, rr, 64);
+		const uint64_t r_low = ((uint64_t) (uint32_t) __shfl((int) (low0 >> 32), rr, 64) << 32) | (uint32_t) __shfl((int) low0, rr, 64);
+		const uint64_t r_bits = ((uint64_t) (uint32_t) __shfl((int) (nbits >> 32), rr, 64) << 32) | (uint32_t) __shfl((int) nbits, rr, 64);
+		for (uint32_t t = lane; t < r_nt; t += 64) {
 			HufTile d;
-			d.src = a.in_off[r] + hdr + t * (TB / 8);
-			d.low = a.off[r];
-			d.nbits = (uint32_t) (nbits - t * TB);
-			d.t_last = t | (t + 1 == nt ? 0x80000000u : 0u);
-			d.read = r;
-			d.want = m->nlow;
-			a.htiles[base + t] = d;
+			d.src = r_src + t * (TB / 8);
+			d.low = r_low;
+			d.nbits = (uint32_t) (r_bits - t * TB);
+			d.t_last = t | (t + 1 == r_nt ? 0x80000000u : 0u);
+			d.read = r_read;
+			d.want = r_want;
+			a.htiles[r_base + t] = d;
 		}
 	}
 }
