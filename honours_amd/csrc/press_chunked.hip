@@ -677,7 +677,9 @@ __global__ __launch_bounds__(CWG) void k_svb_keyscan(DecodeArgs a)
 template <bool KEY2, bool S5 = false>
 __global__ __launch_bounds__(256) void k_svb_keyprefix(DecodeArgs a)
 {
-	const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+	// one wave per read (see k_ex_prefix)
+	const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63;
 	if (r >= a.nreads)
 		return;
 	const uint32_t n = a.nsamp[r];
@@ -687,17 +689,26 @@ __global__ __launch_bounds__(256) void k_svb_keyprefix(DecodeArgs a)
 	const uint64_t in_len = a.in_len[r] - (S5 ? 4 : 0);
 	ChunkDesc *dp = a.chunks + a.first_chunk[r];
 	if (a.in_len[r] < (S5 ? 4u : 0u) || klen > in_len || !dp->cap_ok) { // cap_ok: k_chunk_prep (S5: the count in the stream)
-		a.out_n[r] = CFAIL32;
+		if (lane == 0)
+			a.out_n[r] = CFAIL32;
 		return;
 	}
 	const uint32_t nch = (n + CHUNK - 1) / CHUNK;
 	uint64_t e = 0;
-	for (uint32_t j = 0; j < nch; j++) {
-		dp[j].ebefore = e;
-		e += (uint64_t) dp[j].ecnt[0] + dp[j].ecnt[1] + dp[j].ecnt[2] + dp[j].ecnt[3];
+	for (uint32_t j0 = 0; j0 < nch; j0 += 64) {
+		const uint32_t j = j0 + lane;
+		// (a chunk's count may carry k_svb_keyscan's poison bit 30: the low 20 bits and the rest are summed apart)
+		const uint64_t c = j < nch ? (uint64_t) dp[j].ecnt[0] + dp[j].ecnt[1] + dp[j].ecnt[2] + dp[j].ecnt[3] : 0ull;
+		const uint32_t lo = wave_incl_scan_dpp((uint32_t) (c & 0xFFFFFu)), hi = wave_incl_scan_dpp((uint32_t) (c >> 20));
+		const uint64_t inc = (uint64_t) lo + ((uint64_t) hi << 20);
+		if (j < nch)
+			dp[j].ebefore = e + inc - c;
+		e += (uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) lo, 63) +
+		     ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) hi, 63) << 20);
 	}
 	// slow5_press.c:1098: the decoder must consume exactly the bytes it was given
-	a.out_n[r] = (S5 ? (uint64_t) klen + n + e == in_len : (uint64_t) klen + n + e <= in_len) ? n : CFAIL32;
+	if (lane == 0)
+		a.out_n[r] = (S5 ? (uint64_t) klen + n + e == in_len : (uint64_t) klen + n + e <= in_len) ? n : CFAIL32;
 }
 
 #ifdef DEC_STAMPS
@@ -1967,7 +1978,7 @@ static void run_decode(const DecodeArgs &a, hipStream_t s)
 			   S5 ? 4u : 0u);
 	// surplus workgroups (max_chunks bounds the real count from above) exit at once
 	hipLaunchKernelGGL((k_svb_keyscan<KEY2, S5>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
-	hipLaunchKernelGGL((k_svb_keyprefix<KEY2, S5>), dim3((a.nreads + 255) / 256), dim3(256), 0, s, a);
+	hipLaunchKernelGGL((k_svb_keyprefix<KEY2, S5>), dim3((a.nreads + 3) / 4), dim3(256), 0, s, a);
 	ktime_begin(1, s);
 	hipLaunchKernelGGL((k_svb_decode_chunked<KEY2, ZD, S5>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	ktime_end(1, s);
