@@ -591,8 +591,10 @@ __device__ __forceinline__ uint32_t unzz_pair_hib(uint32_t z, uint32_t hib, int 
 template <bool KEY2, bool S5 = false>
 __global__ __launch_bounds__(CWG) void k_svb_keyscan(DecodeArgs a)
 {
-	const uint32_t c = blockIdx.x;
-	if (c >= a.ctl->nchunks)
+	// one WAVE per chunk, its four quarters one after the other (a workgroup per chunk: four times the waves for
+	// one 16-byte load per lane each)
+	const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (c >= uni(a.ctl->nchunks))
 		return;
 	ChunkDesc *dp = a.chunks + c;
 	if (!uni(dp->cap_ok))
@@ -602,10 +604,14 @@ __global__ __launch_bounds__(CWG) void k_svb_keyscan(DecodeArgs a)
 	const uint64_t in_len = uni64(a.in_len[uni(dp->read)]) - (S5 ? 4 : 0);
 	const uint32_t klen = KEY2 ? (n + 3) / 4 : (n >> 3) + (((n & 7) + 7) >> 3);
 	const int lane = threadIdx.x & 63;
-	const int w = (int) uni(threadIdx.x >> 6);
-	const uint32_t ws = uni(dp->j) * CHUNK + w * WAVE_SAMPLES;
 	constexpr int NL = KEY2 ? 2 : 1;            // 16-byte loads per lane
 	constexpr uint32_t SPB = KEY2 ? 4 : 8;      // samples per key byte
+	const uint32_t cj = uni(dp->j);
+#pragma unroll 1
+	for (int w = 0; w < 4; w++) {
+	const uint32_t ws = cj * CHUNK + w * WAVE_SAMPLES;
+	if (ws >= n && w)
+		break; // (the read ends in an earlier quarter: nothing here - the descriptor's zeros stand)
 	uint32_t cnt = 0;
 	uint32_t kmask = 0;
 	uint32_t bad = 0;
@@ -669,6 +675,7 @@ __global__ __launch_bounds__(CWG) void k_svb_keyscan(DecodeArgs a)
 	if (lane == 0) {
 		dp->ecnt[w] = (uint32_t) (etot > 0xFFFFFFFFull ? 0xFFFFFFFFull : etot);
 		dp->kmask[w] = (uint16_t) kmask;
+	}
 	}
 }
 
@@ -1977,7 +1984,7 @@ static void run_decode(const DecodeArgs &a, hipStream_t s)
 			   (uint64_t *) nullptr, a.out_n, a.first_chunk, (ReadMeta *) nullptr, a.in,
 			   S5 ? 4u : 0u);
 	// surplus workgroups (max_chunks bounds the real count from above) exit at once
-	hipLaunchKernelGGL((k_svb_keyscan<KEY2, S5>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
+	hipLaunchKernelGGL((k_svb_keyscan<KEY2, S5>), dim3((a.max_chunks + 3) / 4), dim3(CWG), 0, s, a);
 	hipLaunchKernelGGL((k_svb_keyprefix<KEY2, S5>), dim3((a.nreads + 3) / 4), dim3(256), 0, s, a);
 	ktime_begin(1, s);
 	hipLaunchKernelGGL((k_svb_decode_chunked<KEY2, ZD, S5>), dim3(a.max_chunks), dim3(CWG), 0, s, a);
