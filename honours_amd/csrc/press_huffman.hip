@@ -239,7 +239,21 @@ __device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint32_t
 	return bad ? HEND : (p >= nb && p < lim ? HEND : p);
 }
 
+// make the LDS writes of this wave visible to its other lanes (DS ops of a wave execute in
+// order; this only stops the compiler from moving them)
+__device__ __forceinline__ void wave_lds_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------ one tile
+
+// two tiles side by side share the tables (48 KiB of LDS per workgroup: three on a CU)
+constexpr int SG = 2;
+constexpr int WGS = SG * HT;
+constexpr int WGS_MAX = WGS;
 
 template <int RU>
 struct TileLds { // what a workgroup keeps per tile besides the tables
@@ -248,22 +262,49 @@ struct TileLds { // what a workgroup keeps per tile besides the tables
 	// one row behind the last column for len_scan's prefetch
 	uint32_t img[HT / 64 + 1][NCOL * 64];
 	uint32_t pad_row[64];
-	uint16_t s_d[HT];
-	uint8_t s_f[HT], s_e[HT], s_c[HT], s_list[HT];
-	uint32_t s_nl[2];
-	uint32_t wtot[HT / 64], wdt[HT / 64];
+	uint8_t s_e[HT];
 };
 
-constexpr uint32_t NO_START = 0xFFu;
+// what k_huf_sync / k_huf_fix leave per subsequence: a.hrec = start | codes << 8 | sum of their deltas << 16,
+// a.hend = where the next subsequence's first code starts (0 .. 30, R_END: none)
+__device__ __forceinline__ uint32_t pack_rec(uint32_t f, uint32_t c, uint32_t d)
+{
+	return (f == HEND ? R_END : f) | ((c & 0xFFu) << 8) | ((d & 0xFFFFu) << 16);
+}
 
-// Tile k, by the 256 threads of group `grp` of the workgroup; the G groups of a workgroup run their
-// tiles side by side and share the barriers (has = false: a group without a tile only keeps them).
-// start: NO_START = the first lane runs up through the tile in front like every other lane; else the
-// position (0 .. 30 / R_END) where the tile's first code starts.  Leaves the subsequences' records in
-// a.hrec, the tile's in a.htrec[k] and its `se` also as the return value (same in every thread of the group).
+constexpr uint32_t LIST_NONE = 0xFFFFFFFFu; // an unused list slot
+constexpr uint32_t LIST_CHUNK = 1024;       // slots a workgroup of k_huf_sync takes from the list at a time
+
+// append the lanes with `yes` to the list whose counter is *cnt (one atomic per wave)
+__device__ __forceinline__ void list_push(uint32_t *list, uint32_t *cnt, uint32_t cap, bool yes, uint32_t value, uint32_t lane)
+{
+	const unsigned long long m = __ballot(yes);
+	if (!m)
+		return;
+	uint32_t base = 0;
+	if (lane == (uint32_t) __builtin_ctzll(m))
+		base = atomicAdd(cnt, (uint32_t) __popcll(m));
+	base = (uint32_t) __shfl((int) base, __builtin_ctzll(m), 64);
+	const uint32_t idx = base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+	if (yes && idx < cap)
+		list[idx] = value;
+}
+
+// Tile k, first pass, by the 256 threads of group `grp` of the workgroup (the G groups of a workgroup run
+// their tiles side by side and share the barriers; has = false: a group without a tile only keeps them): every
+// lane runs up through the half subsequence in front of its own - where that crosses into its subsequence is its
+// guess of the first code's start - and then through its own.  Lanes whose guess is not where the left neighbour
+// ended go on the list of k_huf_fix; nothing is repaired here (while one wave decoded a tile's two or three such
+// lanes again, the other seven of the workgroup waited: a quarter of this kernel's time).
+struct SyncList { // a workgroup's place in the list of k_huf_fix (LDS)
+	uint32_t pos, end;       // its current chunk: next free slot, end
+	uint32_t wcnt[WGS_MAX / 64]; // this round: entries of every wave
+	uint32_t old, rem, nbase; // ... and where they go: `rem` into the old chunk from `old`, the rest from `nbase`
+};
+
 template <int RU, int G>
-__device__ __forceinline__ uint32_t sync_tile(const DecodeArgs &a, uint32_t k, bool has, uint32_t start,
-					      TileLds<RU> *TT, const uint32_t *lut, const uint16_t *lut2)
+__device__ __forceinline__ void sync_tile(const DecodeArgs &a, uint32_t k, bool has, TileLds<RU> *TT,
+					  const uint32_t *lut, const uint16_t *lut2, SyncList &SL)
 {
 	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW;
 	const uint32_t grp = G > 1 ? uniform(threadIdx.x >> 8) : 0u;
@@ -277,14 +318,12 @@ __device__ __forceinline__ uint32_t sync_tile(const DecodeArgs &a, uint32_t k, b
 	const int32_t nby = (int32_t) ((nbits_t + 7) >> 3); // (nbits_t < 2^32: below 2^29 bytes)
 	uint32_t *col = T.img[(tid >> 6) + 1] + lane;
 	const uint32_t *rcol = T.img[(tid + 63) >> 6] + ((tid + 63) & 63); // the left neighbour's column
-	const bool exact = t == 0 || start != NO_START; // the first lane's start is known
+	const bool exact = t == 0; // the first lane's start is known: the read's payload starts here
 
 	col_load<NDW>(col, src, (int32_t) tid * (OWN / 8), 0, nby);
 	if (tid == 0 && !exact) // the bits in front of the tile belong to the same payload
 		col_load<NDW>(T.img[0] + 63, src, -(OWN / 8), -(OWN / 8), nby);
-	if (tid == 0)
-		T.s_nl[0] = T.s_nl[1] = 0;
-	__syncthreads(); // columns (a lane's run-up reads its neighbour's) - and whatever the caller staged
+	__syncthreads(); // columns (a lane's run-up reads its neighbour's)
 	// payload end in the coordinates of the own / the neighbour's column
 	const uint32_t nb = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN);
 	const uint32_t nbr = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN + OWN);
@@ -298,96 +337,53 @@ __device__ __forceinline__ uint32_t sync_tile(const DecodeArgs &a, uint32_t k, b
 		if (g == HEND && nb > 0)
 			f = 0; // the guess ran into a bit pattern that is no code: any guess will do
 		if (first_known)
-			f = t == 0 ? 0u : (start == R_END ? HEND : start);
+			f = 0;
 	}
 	const uint32_t e = len_scan(col, lut, lut2, a.huff, f, OWN, nb, c, dv);
-	T.s_f[tid] = (uint8_t) (f == HEND ? R_END : f);
-	T.s_e[tid] = (uint8_t) (e == HEND ? R_END : e - OWN);
-	T.s_c[tid] = (uint8_t) c;
-	T.s_d[tid] = (uint16_t) dv;
-
-	// ---- repair rounds: a lane whose assumed start is not where its left neighbour ended (3 %) is
-	// decoded again from there; thread i is final after at most i rounds, in practice after one or two
-	for (uint32_t par = 0;; par ^= 1u) {
-		__syncthreads();
-		const bool broken = tid > 0 && T.s_f[tid] != T.s_e[tid - 1];
-		const unsigned long long bm = __ballot(broken);
-		if (bm) {
-			uint32_t base = 0;
-			if (lane == 0)
-				base = atomicAdd(&T.s_nl[par], (uint32_t) __popcll(bm));
-			base = (uint32_t) __shfl((int) base, 0, 64);
-			if (broken)
-				T.s_list[base + (uint32_t) __popcll(bm & ((1ull << lane) - 1ull))] = (uint8_t) tid;
-		}
-		if (tid == 0)
-			T.s_nl[par ^ 1u] = 0;
-		__syncthreads();
-		const uint32_t nl = T.s_nl[par];
-		uint32_t nl_any = nl;
-		if (G > 1)
-			nl_any |= TT[grp ^ 1u].s_nl[par];
-		if (nl_any == 0)
-			break;
-		if (tid < 64) {
-			for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
-				const uint32_t i = i0 + tid;
-				const bool mine = i < nl;
-				const uint32_t u = mine ? T.s_list[i] : 1u;
-				const uint32_t pe = T.s_e[u - 1];
-				uint32_t c2, d2;
-				const uint32_t e2 = len_scan(T.img[(u >> 6) + 1] + (u & 63), lut, lut2, a.huff,
-							     (!mine || pe == R_END) ? HEND : pe, OWN,
-							     clamp_nb((int64_t) nbits_t - (int64_t) u * OWN), c2, d2);
-				if (mine) {
-					T.s_f[u] = (uint8_t) pe;
-					T.s_e[u] = (uint8_t) (e2 == HEND ? R_END : e2 - OWN);
-					T.s_c[u] = (uint8_t) c2;
-					T.s_d[u] = (uint16_t) d2;
-				}
-			}
-		}
+	const uint32_t e8 = e == HEND ? R_END : e - OWN;
+	T.s_e[tid] = (uint8_t) e8;
+	const uint32_t cw = wave_scan(c), dw = wave_scan(dv);
+	if (has) {
+		a.hrec[(uint64_t) k * HT + tid] = pack_rec(f, c, dv);
+		a.hend[(uint64_t) k * HT + tid] = (uint8_t) e8;
+		if (lane == 63) // the wave's totals (k_huf_fix adds what its repairs change)
+			a.hwave[(uint64_t) k * (HT / 64) + (tid >> 6)] = make_uint2(cw, dw & 0xFFFFu);
 	}
-
-	// ---- the records: per subsequence {start, codes}, per tile {assumed start, end, codes, deltas}
-	const uint32_t cnt = T.s_c[tid];
-	if (has)
-		a.hrec[(uint64_t) k * HT + tid] = (uint32_t) T.s_f[tid] | (cnt << 8);
-	const uint32_t inc = wave_scan(cnt);
-	const uint32_t dinc = wave_scan((uint32_t) T.s_d[tid]);
-	if (lane == 63) {
-		T.wtot[tid >> 6] = inc;
-		T.wdt[tid >> 6] = dinc & 0xFFFFu;
+	__syncthreads(); // the neighbours' ends; the columns are free again behind this
+	// (the tile's first lane is checked against the tile in front by k_huf_tlinks)
+	const bool broken = has && tid > 0 && (f == HEND ? R_END : f) != T.s_e[tid - 1];
+	// ---- the workgroup's broken lanes go to its chunk of the list: one global atomic per LIST_CHUNK entries
+	// (an atomic per wave - 400 000 on one counter - tripled this kernel's time)
+	const unsigned long long bm = __ballot(broken);
+	const uint32_t wv = threadIdx.x >> 6;
+	if ((threadIdx.x & 63) == 0)
+		SL.wcnt[wv] = (uint32_t) __popcll(bm);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t tot = 0;
+		for (uint32_t w2 = 0; w2 < (uint32_t) (G * HT / 64); w2++)
+			tot += SL.wcnt[w2];
+		const uint32_t rem = SL.end - SL.pos;
+		SL.old = SL.pos;
+		SL.rem = rem;
+		if (tot > rem) { // (tot <= the workgroup's threads <= LIST_CHUNK)
+			const uint32_t nbase = atomicAdd(&a.ctl->ticket2, LIST_CHUNK);
+			SL.nbase = nbase;
+			SL.pos = nbase + (tot - rem);
+			SL.end = nbase + LIST_CHUNK;
+		} else {
+			SL.pos += tot;
+		}
 	}
 	__syncthreads();
-	const uint32_t se = (uint32_t) T.s_f[0] | ((uint32_t) T.s_e[HT - 1] << 8);
-	if (tid == 0 && has) {
-		HufTRec r;
-		r.se = se;
-		r.count = 0;
-		r.dtot = 0;
-#pragma unroll
-		for (int w2 = 0; w2 < HT / 64; w2++) {
-			r.count += T.wtot[w2];
-			r.dtot += T.wdt[w2];
-			r.wd[w2] = (uint16_t) T.wdt[w2];
-		}
-		r.dtot &= 0xFFFFu;
-		r.base = 0;
-		r.dbase = 0;
-		r.fused = 0;
-		a.htrec[k] = r;
+	if (broken) {
+		uint32_t j = (uint32_t) __popcll(bm & ((1ull << lane) - 1ull));
+		for (uint32_t w2 = 0; w2 < wv; w2++)
+			j += SL.wcnt[w2];
+		const uint32_t idx = j < SL.rem ? SL.old + j : SL.nbase + (j - SL.rem);
+		if (idx < a.hlist_cap)
+			a.hlist[idx] = k * HT + tid;
 	}
-	if (tid < HT / 64 && has) { // what the waves in front of wave `tid` hold: k_huf_emit's waves start from here on their own
-		uint32_t cb = 0, db = 0;
-		for (uint32_t w2 = 0; w2 < tid; w2++) {
-			cb += T.wtot[w2];
-			db += T.wdt[w2];
-		}
-		a.hwave[(uint64_t) k * (HT / 64) + tid] = cb | (db << 16);
-	}
-	__syncthreads(); // the columns and lists are free again
-	return se;
 }
 
 __device__ __forceinline__ void load_len_tables(const HuffDev *hd, uint32_t *mlut, uint16_t *l2ld, uint32_t nthr)
@@ -402,73 +398,164 @@ __device__ __forceinline__ void load_len_tables(const HuffDev *hd, uint32_t *mlu
 		u4[i] = t4[i];
 }
 
-// two tiles side by side share the tables (48 KiB of LDS per workgroup: three on a CU)
-constexpr int SG = 2;
-constexpr int WGS = SG * HT;
 
-// All tiles (LIST = false), or the tiles of a repair round: a.hlist = {tile, true start} pairs, their
-// number in ctl->ticket2.  Persistent workgroups: the tables are loaded once.
-template <int RU, bool LIST>
+// All tiles.  Persistent workgroups: the tables are loaded once.
+template <int RU>
 __global__ __launch_bounds__(WGS, 6) void k_huf_sync(DecodeArgs a)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t lut[1 << HUF_LUT_BITS];
 	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
 	__shared__ TileLds<RU> T[SG];
+	__shared__ SyncList SL;
 
-	const uint32_t n = LIST ? min(uniform(a.ctl->ticket2), a.hlist_cap) : min(uniform(a.ctl->nchunks), a.max_htiles);
+	const uint32_t n = min(uniform(a.ctl->nchunks), a.max_htiles);
 	if (SG * blockIdx.x >= n)
 		return;
 	const uint32_t grp = uniform(threadIdx.x >> 8);
+	if (threadIdx.x == 0)
+		SL.pos = SL.end = 0;
 	load_len_tables(a.huff, lut, lut2, WGS);
 	for (uint32_t i0 = SG * blockIdx.x; i0 < n; i0 += SG * gridDim.x) {
 		const uint32_t i = i0 + grp;
 		const bool has = i < n; // (an odd count leaves the last group idle)
-		const uint32_t ii = has ? i : i0;
-		const uint32_t k = LIST ? uniform(a.hlist[2 * ii]) : ii;
-		const uint32_t st = LIST ? uniform(a.hlist[2 * ii + 1]) : NO_START;
-		(void) sync_tile<RU, SG>(a, k, has, st, T, lut, lut2);
+		sync_tile<RU, SG>(a, has ? i : i0, has, T, lut, lut2, SL);
 	}
+	__syncthreads();
+	for (uint32_t j = SL.pos + threadIdx.x; j < SL.end && j < a.hlist_cap; j += WGS) // what is left of the last chunk
+		a.hlist[j] = LIST_NONE;
 }
 
-// tiles whose assumed start is not where the tile in front ended -> a.hlist
+// first lanes of tiles whose guess is not where the tile in front ended -> the list of k_huf_fix
 __global__ __launch_bounds__(256) void k_huf_tlinks(DecodeArgs a)
 {
 	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63;
 	bool br = false;
-	uint32_t pe = 0;
-	if (k < min(a.ctl->nchunks, a.max_htiles) && (a.htiles[k].t_last & 0x7FFFFFFFu)) {
-		pe = (a.htrec[k - 1].se >> 8) & 0xFFu;
-		br = (a.htrec[k].se & 0xFFu) != pe;
-	}
-	const unsigned long long m = __ballot(br);
-	if (m) {
-		uint32_t base = 0;
-		if (lane == 0)
-			base = atomicAdd(&a.ctl->ticket2, (uint32_t) __popcll(m));
-		base = (uint32_t) __shfl((int) base, 0, 64);
-		const uint32_t idx = base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
-		if (br && idx < a.hlist_cap) {
-			a.hlist[2 * idx] = k;
-			a.hlist[2 * idx + 1] = pe;
+	if (k < min(a.ctl->nchunks, a.max_htiles) && (a.htiles[k].t_last & 0x7FFFFFFFu))
+		br = (a.hrec[(uint64_t) k * HT] & 0xFFu) != a.hend[(uint64_t) k * HT - 1];
+	list_push(a.hlist, &a.ctl->ticket2, a.hlist_cap, br, k * HT, lane);
+}
+
+// Subsequences whose start was guessed wrong, 64 to a wave: decoded again from where the subsequence in front
+// ended.  If that moves the subsequence's own end, its right neighbour goes on the next round's list.  Lists:
+// a.hlist[0 .. cap) and a.hlist[cap .. 2 cap) take turns (`round` odd: the second is read), their counts in
+// ctl->ticket2 / ctl->pad2[0].  `last`: what is still pushed marks its read for k_huf_serial (a.hmin).
+constexpr int FIX_WG = 256; // four waves, each on its own, share the tables
+template <int RU>
+__global__ __launch_bounds__(FIX_WG) void k_huf_fix(DecodeArgs a, int round, int last)
+{
+	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW, NCOL = HufGeo<RU>::NCOL;
+	__shared__ __attribute__((aligned(16))) uint32_t lut[1 << HUF_LUT_BITS];
+	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
+	__shared__ uint32_t imgs[FIX_WG / 64][NCOL * 64 + 64];
+
+	const uint32_t *in_list = a.hlist + (round & 1 ? a.hlist_cap : 0u);
+	uint32_t *out_list = a.hlist + (round & 1 ? 0u : a.hlist_cap);
+	uint32_t *in_cnt = round & 1 ? &a.ctl->pad2[0] : &a.ctl->ticket2;
+	uint32_t *out_cnt = round & 1 ? &a.ctl->ticket2 : &a.ctl->pad2[0];
+	const uint32_t n = min(uniform(*in_cnt), a.hlist_cap);
+	if ((uint32_t) FIX_WG * blockIdx.x >= n)
+		return;
+	const uint32_t lane = threadIdx.x & 63;
+	load_len_tables(a.huff, lut, lut2, FIX_WG);
+	uint32_t *col = imgs[threadIdx.x >> 6] + lane;
+	for (uint32_t i0 = FIX_WG * blockIdx.x + (threadIdx.x & ~63u); i0 < n; i0 += (uint32_t) FIX_WG * gridDim.x) {
+		uint32_t ent = i0 + lane < n ? in_list[i0 + lane] : LIST_NONE;
+		const bool mine = ent != LIST_NONE;
+		const uint64_t g = mine ? ent : 1u;
+		const uint32_t k = (uint32_t) (g / HT), tid = (uint32_t) (g % HT);
+		const HufTile *dp = a.htiles + k;
+		const uint32_t nbits_t = mine ? dp->nbits : 0u;
+		wave_lds_sync();
+		if (mine)
+			col_load<NDW>(col, a.in + dp->src, (int32_t) tid * (OWN / 8), 0, (int32_t) ((nbits_t + 7) >> 3));
+		wave_lds_sync();
+		// the true start: where the subsequence in front ended (the first of a read never comes here)
+		const uint32_t pe = mine ? a.hend[g - 1] : R_END;
+		const uint32_t old_e = mine ? a.hend[g] : R_END;
+		uint32_t c2, d2;
+		const uint32_t e2 = len_scan(col, lut, lut2, a.huff, (!mine || pe == R_END) ? HEND : pe, OWN,
+					     clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN), c2, d2);
+		const uint32_t e8 = e2 == HEND ? R_END : e2 - OWN;
+		bool next = false;
+		if (mine) {
+			const uint32_t old = a.hrec[g];
+			a.hrec[g] = pack_rec(pe == R_END ? HEND : pe, c2, d2);
+			// the wave's totals follow, both in one 64-bit add (the count's borrows and carries cancel)
+			const long long dc = (long long) (int32_t) (c2 - ((old >> 8) & 0xFFu));
+			const unsigned long long dd = (d2 - (old >> 16)) & 0xFFFFu;
+			if (dc != 0 || dd != 0)
+				atomicAdd(reinterpret_cast<unsigned long long *>(a.hwave + (uint64_t) k * (HT / 64) + (tid >> 6)),
+					  (dd << 32) + (unsigned long long) dc);
+			if (e8 != old_e) {
+				a.hend[g] = (uint8_t) e8;
+				// the right neighbour, if the read has one, started from the old end
+				const bool more = tid + 1 < HT || !(dp->t_last >> 31);
+				next = more && (uint64_t) tid * OWN + OWN < nbits_t;
+			}
 		}
+		list_push(out_list, out_cnt, a.hlist_cap, next, (uint32_t) g + 1, lane);
+		if (last && next)
+			atomicMin(&a.hmin[dp->read], (uint32_t) g + 1);
+	}
+}
+
+// What k_huf_fix's rounds left (a code whose lengths share a factor never synchronises; an ordinary table is
+// through after two rounds): one wave per marked read walks its subsequences from the first unsettled one,
+// serially - slow and always right.
+template <int RU>
+__global__ __launch_bounds__(64) void k_huf_serial(DecodeArgs a)
+{
+	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW, NCOL = HufGeo<RU>::NCOL;
+	__shared__ __attribute__((aligned(16))) uint32_t lut[1 << HUF_LUT_BITS];
+	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
+	__shared__ uint32_t img[NCOL * 64 + 64];
+
+	const uint32_t r = blockIdx.x;
+	const uint32_t g0 = uniform(a.hmin[r]);
+	if (g0 == 0xFFFFFFFFu)
+		return;
+	const uint32_t lane = threadIdx.x;
+	const uint32_t k0 = uniform(a.hread[2 * r]), nt = uniform(a.hread[2 * r + 1]);
+	load_len_tables(a.huff, lut, lut2, 64);
+	uint32_t *col = img + lane;
+	const uint64_t gend = (uint64_t) (k0 + nt) * HT;
+	for (uint64_t g = g0; g < gend; g++) {
+		const uint32_t k = (uint32_t) (g / HT), tid = (uint32_t) (g % HT);
+		const HufTile *dp = a.htiles + k;
+		const uint32_t nbits_t = uniform(dp->nbits);
+		if ((uint64_t) tid * OWN >= nbits_t)
+			break; // behind the payload
+		const uint32_t pe = uniform((uint32_t) __hip_atomic_load(a.hend + g - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		const uint32_t rec = uniform(__hip_atomic_load(a.hrec + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		if ((rec & 0xFFu) == pe)
+			continue; // this link holds
+		wave_lds_sync();
+		if (lane == 0)
+			col_load<NDW>(col, a.in + dp->src, (int32_t) tid * (OWN / 8), 0, (int32_t) ((nbits_t + 7) >> 3));
+		wave_lds_sync();
+		uint32_t c2, d2;
+		const uint32_t e2 = len_scan(col, lut, lut2, a.huff, (lane || pe == R_END) ? HEND : pe, OWN,
+					     clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN), c2, d2);
+		if (lane == 0) {
+			a.hrec[g] = pack_rec(pe == R_END ? HEND : pe, c2, d2);
+			atomicAdd(reinterpret_cast<unsigned long long *>(a.hwave + (uint64_t) k * (HT / 64) + (tid >> 6)),
+				  ((unsigned long long) ((d2 - (rec >> 16)) & 0xFFFFu) << 32) +
+					  (unsigned long long) (long long) (int32_t) (c2 - ((rec >> 8) & 0xFFu)));
+			__hip_atomic_store(a.hend + g, (uint8_t) (e2 == HEND ? R_END : e2 - OWN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 	}
 }
 
 // the delta a 16-bit zig-zag value stands for, mod 2^16 (trans.c:80)
 __device__ __forceinline__ uint32_t unzz16(uint32_t z) { return ((z >> 1) ^ (0u - (z & 1u))) & 0xFFFFu; }
 
-// One workgroup per read: repair what the rounds left (serially - always correct), then the codes and
-// the sum of the deltas in front of every tile, what the read delivers (huffman.c:1243: at most `want`
-// values), the running sum of the exceptions' deltas (into the upper half of ex_val) and whether
-// k_huf_emit may write the samples itself.
-template <int RU>
-__global__ __launch_bounds__(HT, 4) void k_huf_chain(DecodeArgs a)
+// One workgroup per read: the codes and the sum of the deltas in front of every tile, what the read delivers
+// (huffman.c:1243: at most `want` values), the running sum of the exceptions' deltas (into the upper half of
+// ex_val) and whether k_huf_emit may write the samples itself.
+__global__ __launch_bounds__(HT) void k_huf_chain(DecodeArgs a)
 {
-	__shared__ __attribute__((aligned(16))) uint32_t lut[1 << HUF_LUT_BITS];
-	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
-	__shared__ TileLds<RU> T;
-	__shared__ uint32_t s_first;
 	__shared__ uint32_t s_w[HT / 64], s_wd[HT / 64];
 
 	const uint32_t r = blockIdx.x;
@@ -476,45 +563,18 @@ __global__ __launch_bounds__(HT, 4) void k_huf_chain(DecodeArgs a)
 	const uint32_t k0 = uniform(a.hread[2 * r]), nt = uniform(a.hread[2 * r + 1]);
 	if (!nt)
 		return;
-	bool loaded = false;
-	for (uint32_t t0 = 1; t0 < nt;) {
-		// the first broken link at or behind t0
-		if (tid == 0)
-			s_first = 0xFFFFFFFFu;
-		__syncthreads();
-		for (uint32_t u = t0 + tid; u < nt; u += HT)
-			if ((a.htrec[k0 + u].se & 0xFFu) != ((a.htrec[k0 + u - 1].se >> 8) & 0xFFu)) {
-				atomicMin(&s_first, u);
-				break;
-			}
-		__syncthreads();
-		uint32_t u = s_first;
-		__syncthreads();
-		if (u == 0xFFFFFFFFu)
-			break;
-		if (!loaded) {
-			load_len_tables(a.huff, lut, lut2, HT); // (sync_tile's first barrier covers it)
-			loaded = true;
-		}
-		// decode from the true start, and on while that moves the end
-		uint32_t pe = (a.htrec[k0 + u - 1].se >> 8) & 0xFFu;
-		for (;;) {
-			const uint32_t se = sync_tile<RU, 1>(a, k0 + u, true, pe, &T, lut, lut2);
-			pe = (se >> 8) & 0xFFu;
-			u++;
-			if (u >= nt || (a.htrec[k0 + u].se & 0xFFu) == pe)
-				break;
-		}
-		t0 = u + 1;
-	}
 	// exclusive prefix of the tiles' counts and delta sums
 	uint64_t cum = 0;
 	uint32_t dcum = 0;
 	for (uint32_t b = 0; b < nt; b += HT) {
 		const uint32_t u = b + tid;
-		// (tiles decoded again above: read past this CU's L1, which may hold the records as they were)
-		const uint32_t c = u < nt ? __hip_atomic_load(&a.htrec[k0 + u].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-		const uint32_t dt = u < nt ? __hip_atomic_load(&a.htrec[k0 + u].dtot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+		uint32_t c = 0, dt = 0;
+		if (u < nt) { // the tile's totals: its four waves'
+			const uint4 *wp = reinterpret_cast<const uint4 *>(a.hwave + (uint64_t) (k0 + u) * (HT / 64));
+			const uint4 w01 = wp[0], w23 = wp[1];
+			c = w01.x + w01.z + w23.x + w23.z;
+			dt = (w01.y + w01.w + w23.y + w23.w) & 0xFFFFu;
+		}
 		const uint32_t inc = wave_scan(c);
 		const uint32_t dinc = wave_scan(dt);
 		if ((tid & 63) == 63) {
@@ -575,6 +635,7 @@ __global__ __launch_bounds__(HT, 4) void k_huf_chain(DecodeArgs a)
 	const bool fused = nlow >= 1 && (nex == 0 || a.ex_pos[o0 + nex - 1] < nlow + nex);
 	for (uint32_t u = tid; u < nt; u += HT)
 		a.htrec[k0 + u].fused = fused ? 1u : 0u;
+	static_assert(HT / 64 == 4, "a tile's wave totals are two 16-byte loads");
 	if (tid == 0) {
 		a.meta[r].nlow = nlow;
 		if (fused)
@@ -583,15 +644,6 @@ __global__ __launch_bounds__(HT, 4) void k_huf_chain(DecodeArgs a)
 }
 
 // ------------------------------------------------------------------ k_huf_emit
-
-// make the LDS writes of this wave visible to its other lanes (DS ops of a wave execute in
-// order; this only stops the compiler from moving them)
-__device__ __forceinline__ void wave_lds_sync()
-{
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 constexpr uint32_t EMIT_STG = 3328; // staging bytes per wave: 52 per lane (NA12878: 47.4 on average, 64 at most)
 
@@ -930,7 +982,8 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 		const uint4 *rp = reinterpret_cast<const uint4 *>(a.htrec + (has ? k : k0));
 		const uint4 t0 = tp[0], t1 = tp[1], r0 = rp[0], r1 = rp[1];
 		const uint32_t rec = has ? a.hrec[(uint64_t) k * HT + tid] : R_END;
-		const uint32_t hw = a.hwave[(uint64_t) k * (HT / 64) + (tid >> 6)];
+		const uint4 *hwp = reinterpret_cast<const uint4 *>(a.hwave + (uint64_t) k * (HT / 64));
+		const uint4 hw01 = hwp[0], hw23 = hwp[1]; // the totals {codes, deltas} of the tile's four waves
 		static_assert(sizeof(HufTile) == 32 && sizeof(HufTRec) == 32 && sizeof(ReadMeta) == 32, "records are two 16-byte loads");
 		const uint4 *mp = reinterpret_cast<const uint4 *>(a.meta + uniform(t1.z)); // HufTile::read
 		const uint4 m0 = mp[0], m1 = mp[1];
@@ -940,12 +993,15 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 		const uint64_t roff = ((uint64_t) uniform(t0.w) << 32) | uniform(t0.z);       // ::low: the read's slot - samples
 		uint8_t *low = a.low + roff;                                                  // in a.sig, one-byte values in a.low, exceptions
 		col_load<NDW>(col, src, (int32_t) tid * (OWN / 8), 0, (int32_t) ((nbits_t + 7) >> 3));
-		const uint32_t cnt = rec >> 8;
+		const uint32_t cnt = (rec >> 8) & 0xFFu;
 		const uint32_t inc = wave_scan(cnt);
 		// HufTRec::base, ::dbase: codes of the read in front of the tile and the sum of their deltas; hwave: the same
 		// of the tile's waves in front of this one
-		const uint64_t obase = (uint64_t) uniform(r0.z) + (uniform(hw) & 0xFFFFu);
-		const uint32_t B0 = uniform(r0.w) + (uniform(hw) >> 16);
+		const uint32_t wq = tid >> 6; // what the tile's waves in front of this one hold
+		const uint32_t cb = (wq > 0 ? uniform(hw01.x) : 0u) + (wq > 1 ? uniform(hw01.z) : 0u) + (wq > 2 ? uniform(hw23.x) : 0u);
+		const uint32_t db = (wq > 0 ? uniform(hw01.y) : 0u) + (wq > 1 ? uniform(hw01.w) : 0u) + (wq > 2 ? uniform(hw23.y) : 0u);
+		const uint64_t obase = (uint64_t) uniform(r0.z) + cb;
+		const uint32_t B0 = uniform(r0.w) + (db & 0xFFFFu);
 		const bool fused = has && uniform(r1.w) != 0; // ::fused
 		const uint32_t wsum = uniform((uint32_t) __shfl((int) inc, 63, 64));
 		// the wave delivers values [obase, obase + wsum) of the read, cut at `want`
@@ -1082,6 +1138,8 @@ __global__ __launch_bounds__(256) void k_huff_tiles(DecodeArgs a)
 	}
 }
 
+constexpr int HUF_FIX_LAUNCHES = 4; // rounds of k_huf_fix (an ordinary table is through after two)
+
 template <int RU>
 static void run_huff_decode(const DecodeArgs &a, hipStream_t s)
 {
@@ -1089,13 +1147,16 @@ static void run_huff_decode(const DecodeArgs &a, hipStream_t s)
 	const uint32_t nt = a.max_htiles ? a.max_htiles : 1;
 	const uint32_t grid = (nt + 1) / 2 < 3u * 256u ? (nt + 1) / 2 : 3u * 256u;
 	const uint32_t ge = (nt + 1) / 2 < 2u * 256u ? (nt + 1) / 2 : 2u * 256u;
-	hipLaunchKernelGGL((k_huf_sync<RU, false>), dim3(grid), dim3(WGS), 0, s, a);
-	for (int round = 0; round < HUF_FIX_ROUNDS; round++) {
-		(void) hipMemsetAsync(&a.ctl->ticket2, 0, 4, s);
-		hipLaunchKernelGGL(k_huf_tlinks, dim3((nt + 255) / 256), dim3(256), 0, s, a);
-		hipLaunchKernelGGL((k_huf_sync<RU, true>), dim3(grid), dim3(WGS), 0, s, a);
+	hipLaunchKernelGGL((k_huf_sync<RU>), dim3(grid), dim3(WGS), 0, s, a);
+	hipLaunchKernelGGL(k_huf_tlinks, dim3((nt + 255) / 256), dim3(256), 0, s, a);
+	(void) hipMemsetAsync(a.hmin, 0xFF, (size_t) a.nreads * 4, s);
+	for (int round = 0; round < HUF_FIX_LAUNCHES; round++) {
+		// (the list this round fills: its count starts at zero)
+		(void) hipMemsetAsync(round & 1 ? &a.ctl->ticket2 : &a.ctl->pad2[0], 0, 4, s);
+		hipLaunchKernelGGL((k_huf_fix<RU>), dim3(1280), dim3(FIX_WG), 0, s, a, round, round + 1 == HUF_FIX_LAUNCHES ? 1 : 0);
 	}
-	hipLaunchKernelGGL((k_huf_chain<RU>), dim3(a.nreads), dim3(HT), 0, s, a);
+	hipLaunchKernelGGL((k_huf_serial<RU>), dim3(a.nreads), dim3(64), 0, s, a);
+	hipLaunchKernelGGL(k_huf_chain, dim3(a.nreads), dim3(HT), 0, s, a);
 	hipLaunchKernelGGL((k_huf_emit<RU>), dim3(ge), dim3(WGE), 0, s, a);
 }
 

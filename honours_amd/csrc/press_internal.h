@@ -68,8 +68,6 @@ constexpr uint32_t HUF_TWO = 1u << 29;
 
 // parallel Huffman decode (press_huffman.hip): tiles of HUF_HT subsequences, one workgroup each
 constexpr int HUF_HT = 256;        // threads per workgroup = subsequences per tile
-constexpr int HUF_FIX_ROUNDS = 1;  // parallel tile repair rounds before the serial pass of k_huf_chain (a second
-                                   // round costs 13 us and saves the chain nothing measurable: 0.1 % of the tiles)
 struct HufTRec {             // what k_huf_sync leaves per tile (32 bytes)
 	uint32_t se;         // start it assumed | where the next tile's first code starts << 8 (0 .. 30, 31 = none)
 	uint32_t count;      // codes that start in the tile
@@ -168,10 +166,12 @@ struct DecodeArgs {
 	// Huffman tiles (press_huffman.hip)
 	HufTile *htiles;          // [max_htiles]
 	HufTRec *htrec;           // [max_htiles]
-	uint32_t *hrec;           // [max_htiles * HUF_HT] one record per subsequence: start | codes << 8
-	uint32_t *hlist;          // [2 * hlist_cap] tiles of a repair round: {tile, true start}
+	uint32_t *hrec;           // [max_htiles * HUF_HT] one record per subsequence: start | codes << 8 | sum of their deltas << 16
+	uint32_t *hlist;          // [2 * hlist_cap] two lists of subsequences to decode again (k_huf_fix)
+	uint8_t *hend;            // [max_htiles * HUF_HT] per subsequence: where the next one's first code starts (0 .. 30, 31: none)
+	uint32_t *hmin;           // [nreads] first subsequence k_huf_fix's rounds left unsettled (0xFFFFFFFF: none)
 	uint32_t *hread;          // [2 * nreads] first tile, number of tiles of read r
-	uint32_t *hwave;          // [max_htiles * 4] per wave of a tile: codes | sum of their deltas << 16 of the tile's waves in front of it
+	uint2 *hwave;             // [max_htiles * 4] per wave of a tile: its codes, the sum of their deltas (mod 2^16 in the low half)
 	uint32_t max_htiles;
 	uint32_t hlist_cap;
 	uint32_t huf_minlen;      // shortest code of the table (selects the subsequence size on the host)
