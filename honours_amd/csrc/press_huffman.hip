@@ -10,27 +10,31 @@
 //                LDS look-up takes every whole code that fits in 12 bits.  Lane i runs through the RU = OWN/2 bits in front of its subsequence from
 //                their first bit: where that run crosses into its own subsequence is its guess of the
 //                first code's start (right in ~97 % of the cases); then through its own subsequence.
-//                Lanes whose guess is not where the left neighbour ended are decoded again from there -
-//                by wave 0, which takes the tile's few such lanes together - until every link of the
-//                tile holds.  Leaves a record per subsequence {start, codes} and per tile {start it
-//                assumed, where the next tile's first code starts, codes}.
+//                Leaves a record per subsequence {start, codes, sum of their deltas}, where it ended, and
+//                per wave of a tile the totals; lanes whose guess is not where the left neighbour ended
+//                (~3 %) go on a list - nothing is repaired here (a wave repairing the tile's two or three such
+//                lanes while seven others waited at the barrier was a quarter of this kernel).
 //                The lane's bits live in a private LDS column (dword j of lane l at j*64 + l: any mix
 //                of per-lane positions is bank-conflict free); a lane's run-up reads its neighbour's.
 //                The loops are wave-uniform with predicated bodies; while 12 bits are left in front of
 //                the limit nothing can step over it, so the body is one look-up fed from a register
 //                window over the column (the dword behind the window is fetched while the look-up is in
 //                flight); the last few codes take a careful loop.
-//   k_huf_tlinks tiles whose assumed start is not where the tile in front ended (3 %) are listed and
-//   k_huf_sync   done again from the true start (the same kernel over the list).
-//   k_huf_chain  one workgroup per read: what is still broken is repaired serially, tile after tile
-//                (this alone is enough for ANY table and stream - a code whose lengths share a factor
-//                never synchronises - the rounds before it are only faster); then the codes in front
-//                of every tile and what the read delivers.
+//   k_huf_tlinks the same check for the first lane of every tile against the tile in front.
+//   k_huf_fix    the listed subsequences, 64 to a wave - dense, whatever tile they came from: decoded again from
+//                where the subsequence in front ended; the wave totals take the difference (one 64-bit atomic);
+//                if the subsequence's own end moved, its right neighbour goes on the next round's list.  Four
+//                launches; an ordinary table is through after two (900 000 -> 30 000 -> 900 -> 20 entries).
+//   k_huf_serial what is listed after that (a code whose lengths share a factor never synchronises): one wave
+//                per such read walks it serially from the first unsettled subsequence - slow, enough for ANY
+//                table and stream; the rounds before it are only faster.
+//   k_huf_chain  one workgroup per read: the codes in front of every tile (scan of the wave totals), the sample
+//                value there, what the read delivers, and whether k_huf_emit can write its samples.
 //   k_huf_emit   lane i decodes its subsequence once more from its true start, now with the two-symbol
 //                table, into the wave's LDS staging buffer at its final order (scan of the counts); the
 //                count k_huf_sync found ends the loop.  Every wave is on its own (no barrier in the loop).
 //                The one-byte values do not leave the chip: k_huf_sync also summed the sample deltas they
-//                stand for (per wave and tile, from the same look-up), k_huf_chain made those the sample
+//                stand for (per wave, from the same look-up), k_huf_chain made those the sample
 //                value in front of every tile, so the wave turns its staging buffer into samples itself
 //                (zig-zag, running sum, the few exceptions merged in - trans.c:260) and stores int16.
 //                Reads whose lists do not interleave cleanly (a stream that delivers fewer values than
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(256) void k_huf_tlinks(DecodeArgs a)
 // Subsequences whose start was guessed wrong, 64 to a wave: decoded again from where the subsequence in front
 // ended.  If that moves the subsequence's own end, its right neighbour goes on the next round's list.  Lists:
 // a.hlist[0 .. cap) and a.hlist[cap .. 2 cap) take turns (`round` odd: the second is read), their counts in
-// ctl->ticket2 / ctl->pad2[0].  `last`: what is still pushed marks its read for k_huf_serial (a.hmin).
+// ctl->ticket2 / ctl->list2.  `last`: what is still pushed marks its read for k_huf_serial (a.hmin).
 constexpr int FIX_WG = 256; // four waves, each on its own, share the tables
 template <int RU>
 __global__ __launch_bounds__(FIX_WG) void k_huf_fix(DecodeArgs a, int round, int last)
@@ -451,8 +455,8 @@ __global__ __launch_bounds__(FIX_WG) void k_huf_fix(DecodeArgs a, int round, int
 
 	const uint32_t *in_list = a.hlist + (round & 1 ? a.hlist_cap : 0u);
 	uint32_t *out_list = a.hlist + (round & 1 ? 0u : a.hlist_cap);
-	uint32_t *in_cnt = round & 1 ? &a.ctl->pad2[0] : &a.ctl->ticket2;
-	uint32_t *out_cnt = round & 1 ? &a.ctl->ticket2 : &a.ctl->pad2[0];
+	uint32_t *in_cnt = round & 1 ? &a.ctl->list2 : &a.ctl->ticket2;
+	uint32_t *out_cnt = round & 1 ? &a.ctl->ticket2 : &a.ctl->list2;
 	const uint32_t n = min(uniform(*in_cnt), a.hlist_cap);
 	if ((uint32_t) FIX_WG * blockIdx.x >= n)
 		return;
@@ -929,7 +933,8 @@ __device__ __forceinline__ uint32_t zz_bytes(uint32_t d)
 }
 
 // two tiles side by side share the tables
-constexpr int WGE = 2 * HT;
+constexpr int WGE = 512; // eight waves, each on its own, share the tables
+constexpr uint32_t EMIT_UC = 16; // units of work a workgroup takes from the global counter at a time
 
 struct EmitStg { // the waves' staging buffers; emit_samples reads up to 8 bytes in front of / 12 behind a buffer's content
 	uint8_t pre[16];
@@ -938,24 +943,35 @@ struct EmitStg { // the waves' staging buffers; emit_samples reads up to 8 bytes
 };
 
 template <int RU>
-__global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
+__global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 {
-	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW, NCOL = HufGeo<RU>::NCOL;
+	// (a column here: the NDW dwords that are loaded; emit_codes' look-ahead reads up to two rows further - never
+	// used: the next wave's column, or the pad rows)
+	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW, NCOL = HufGeo<RU>::NDW;
+	constexpr uint32_t EW = WGE / 64;
 	__shared__ uint32_t lut[1 << HUF_LUT_BITS];
 	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
-	__shared__ uint32_t img[WGE / 64][NCOL * 64];
-	__shared__ uint32_t pad_row[64];
+	__shared__ uint32_t img[EW][NCOL * 64];
+	__shared__ uint32_t pad_row[2 * 64];
 	__shared__ __attribute__((aligned(16))) EmitStg stg_all;
+	// Units (a quarter of a tile each) are handed out one at a time: ten waves do not spread evenly over four SIMDs,
+	// and with a fixed share per wave the kernel lasted as long as the waves of the crowded SIMDs (1.64 instead of
+	// 1.19 ms).  A wave draws a ticket from the workgroup's LDS counter; ticket t is unit t % EMIT_UC of the
+	// workgroup's chunk t / EMIT_UC, and whoever draws a chunk's first ticket fetches the chunk from the global
+	// counter and posts it (chunk number << 32 | first unit); the others wait for that post.
+	__shared__ unsigned long long s_chunk[64];
+	__shared__ uint32_t s_ticket;
 
-	const uint32_t grp = threadIdx.x >> 8;
-	const uint32_t tid = threadIdx.x & 255u;
-	const uint32_t lane = tid & 63;
+	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wv = threadIdx.x >> 6; // wave of the workgroup
 	const uint32_t ntiles = min(uniform(a.ctl->nchunks), a.max_htiles);
-	if (2 * blockIdx.x >= ntiles)
-		return;
-	if (threadIdx.x == 0)
-		pad_row[0] = 0; // (keeps the row behind the columns alive)
+	const uint32_t nunits = ntiles * (HT / 64); // a wave's unit of work: a quarter of a tile
+	if (threadIdx.x == 0) {
+		pad_row[0] = 0; // (keeps the rows behind the columns alive)
+		s_ticket = 0;
+	}
+	if (threadIdx.x < 64)
+		s_chunk[threadIdx.x] = ~0ull;
 	{
 		const uint4 *s4 = reinterpret_cast<const uint4 *>(a.huff->lut32);
 		uint4 *d4 = reinterpret_cast<uint4 *>(lut);
@@ -971,11 +987,29 @@ __global__ __launch_bounds__(WGE, 4) void k_huf_emit(DecodeArgs a)
 	__syncthreads(); // the tables; from here on every wave is on its own: columns and staging are private, and
 	                 // what the other waves of its tile hold in front of it comes with the tile's records
 	// persistent workgroups: the tables are loaded once
-	for (uint32_t k0 = 2 * blockIdx.x; k0 < ntiles; k0 += 2 * gridDim.x) {
-		const uint32_t k = k0 + grp;
-		const bool has = k < ntiles; // (an odd tile count leaves the last group idle)
-		if (!has)
+	for (;;) {
+		uint32_t u = 0;
+		if (lane == 0) {
+			const uint32_t t = atomicAdd(&s_ticket, 1u);
+			const uint32_t c = t / EMIT_UC, slot = t % EMIT_UC;
+			unsigned long long *cs = &s_chunk[c & 63u];
+			if (slot == 0) {
+				u = atomicAdd(&a.ctl->units, EMIT_UC);
+				__hip_atomic_store(cs, ((unsigned long long) c << 32) | u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			} else {
+				unsigned long long v;
+				do {
+					v = __hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				} while ((uint32_t) (v >> 32) != c);
+				u = (uint32_t) v + slot;
+			}
+		}
+		u = uniform(u);
+		if (u >= nunits)
 			break;
+		const uint32_t k = u / (HT / 64), k0 = k;
+		const uint32_t tid = (u % (HT / 64)) * 64 + lane; // the lane's subsequence of the tile
+		const bool has = true;
 		// the tile's two records in four loads issued together, then (their `read`) the read's: two memory round
 		// trips for everything the tile needs - field by field they were a dozen, each waited for
 		const uint4 *tp = reinterpret_cast<const uint4 *>(a.htiles + (has ? k : k0));
@@ -1146,18 +1180,19 @@ static void run_huff_decode(const DecodeArgs &a, hipStream_t s)
 	// persistent workgroups: what is resident (sync: 3 per CU, emit: 2, both of two tiles)
 	const uint32_t nt = a.max_htiles ? a.max_htiles : 1;
 	const uint32_t grid = (nt + 1) / 2 < 3u * 256u ? (nt + 1) / 2 : 3u * 256u;
-	const uint32_t ge = (nt + 1) / 2 < 2u * 256u ? (nt + 1) / 2 : 2u * 256u;
+	const uint32_t nge = (nt * (HT / 64) + WGE / 64 - 1) / (WGE / 64);
+	const uint32_t ge = nge < 2u * 256u ? nge : 2u * 256u;
 	hipLaunchKernelGGL((k_huf_sync<RU>), dim3(grid), dim3(WGS), 0, s, a);
 	hipLaunchKernelGGL(k_huf_tlinks, dim3((nt + 255) / 256), dim3(256), 0, s, a);
 	(void) hipMemsetAsync(a.hmin, 0xFF, (size_t) a.nreads * 4, s);
 	for (int round = 0; round < HUF_FIX_LAUNCHES; round++) {
 		// (the list this round fills: its count starts at zero)
-		(void) hipMemsetAsync(round & 1 ? &a.ctl->ticket2 : &a.ctl->pad2[0], 0, 4, s);
+		(void) hipMemsetAsync(round & 1 ? &a.ctl->ticket2 : &a.ctl->list2, 0, 4, s);
 		hipLaunchKernelGGL((k_huf_fix<RU>), dim3(1280), dim3(FIX_WG), 0, s, a, round, round + 1 == HUF_FIX_LAUNCHES ? 1 : 0);
 	}
 	hipLaunchKernelGGL((k_huf_serial<RU>), dim3(a.nreads), dim3(64), 0, s, a);
 	hipLaunchKernelGGL(k_huf_chain, dim3(a.nreads), dim3(HT), 0, s, a);
-	hipLaunchKernelGGL((k_huf_emit<RU>), dim3(ge), dim3(WGE), 0, s, a);
+	hipLaunchKernelGGL((k_huf_emit<RU>), dim3(ge), dim3(WGE), 0, s, a); // (ctl->units: zero since the control block was cleared)
 }
 
 // Huffman stage of the exception-split decoders: payload of every read -> a.low
