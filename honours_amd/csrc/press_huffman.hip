@@ -20,7 +20,7 @@
 //                the limit nothing can step over it, so the body is one look-up fed from a register
 //                window over the column (the dword behind the window is fetched while the look-up is in
 //                flight); the last few codes take a careful loop.
-//   k_huf_tlinks the same check for the first lane of every tile against the tile in front.
+//                (The first lane of a tile whose left neighbour another workgroup holds is listed unchecked.)
 //   k_huf_fix    the listed subsequences, 64 to a wave - dense, whatever tile they came from: decoded again from
 //                where the subsequence in front ended; the wave totals take the difference (one 64-bit atomic);
 //                if the subsequence's own end moved, its right neighbour goes on the next round's list.  Four
@@ -354,8 +354,12 @@ __device__ __forceinline__ void sync_tile(const DecodeArgs &a, uint32_t k, bool 
 			a.hwave[(uint64_t) k * (HT / 64) + (tid >> 6)] = make_uint2(cw, dw & 0xFFFFu);
 	}
 	__syncthreads(); // the neighbours' ends; the columns are free again behind this
-	// (the tile's first lane is checked against the tile in front by k_huf_tlinks)
-	const bool broken = has && tid > 0 && (f == HEND ? R_END : f) != T.s_e[tid - 1];
+	// (the first lane of a tile: against the tile in front if that is the workgroup's other tile; else listed
+	// unchecked - k_huf_fix then starts it from where the tile in front ended, which is only known after this kernel)
+	const uint32_t f8 = f == HEND ? R_END : f;
+	bool broken = has && tid > 0 && f8 != T.s_e[tid - 1];
+	if (tid == 0 && has && !exact)
+		broken = (G > 1 && grp > 0) ? f8 != TT[grp - 1].s_e[HT - 1] : true;
 	// ---- the workgroup's broken lanes go to its chunk of the list: one global atomic per LIST_CHUNK entries
 	// (an atomic per wave - 400 000 on one counter - tripled this kernel's time)
 	const unsigned long long bm = __ballot(broken);
@@ -429,21 +433,10 @@ __global__ __launch_bounds__(WGS, 6) void k_huf_sync(DecodeArgs a)
 		a.hlist[j] = LIST_NONE;
 }
 
-// first lanes of tiles whose guess is not where the tile in front ended -> the list of k_huf_fix
-__global__ __launch_bounds__(256) void k_huf_tlinks(DecodeArgs a)
-{
-	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-	const uint32_t lane = threadIdx.x & 63;
-	bool br = false;
-	if (k < min(a.ctl->nchunks, a.max_htiles) && (a.htiles[k].t_last & 0x7FFFFFFFu))
-		br = (a.hrec[(uint64_t) k * HT] & 0xFFu) != a.hend[(uint64_t) k * HT - 1];
-	list_push(a.hlist, &a.ctl->ticket2, a.hlist_cap, br, k * HT, lane);
-}
-
 // Subsequences whose start was guessed wrong, 64 to a wave: decoded again from where the subsequence in front
 // ended.  If that moves the subsequence's own end, its right neighbour goes on the next round's list.  Lists:
 // a.hlist[0 .. cap) and a.hlist[cap .. 2 cap) take turns (`round` odd: the second is read), their counts in
-// ctl->ticket2 / ctl->list2.  `last`: what is still pushed marks its read for k_huf_serial (a.hmin).
+// ctl->ticket2 (what k_huf_sync listed) and ctl->lists[round] (what this round lists).  `last`: what is still pushed marks its read for k_huf_serial (a.hmin).
 constexpr int FIX_WG = 256; // four waves, each on its own, share the tables
 template <int RU>
 __global__ __launch_bounds__(FIX_WG) void k_huf_fix(DecodeArgs a, int round, int last)
@@ -455,8 +448,8 @@ __global__ __launch_bounds__(FIX_WG) void k_huf_fix(DecodeArgs a, int round, int
 
 	const uint32_t *in_list = a.hlist + (round & 1 ? a.hlist_cap : 0u);
 	uint32_t *out_list = a.hlist + (round & 1 ? 0u : a.hlist_cap);
-	uint32_t *in_cnt = round & 1 ? &a.ctl->list2 : &a.ctl->ticket2;
-	uint32_t *out_cnt = round & 1 ? &a.ctl->ticket2 : &a.ctl->list2;
+	const uint32_t *in_cnt = round ? &a.ctl->lists[round - 1] : &a.ctl->ticket2;
+	uint32_t *out_cnt = &a.ctl->lists[round]; // (zero since the control block was cleared)
 	const uint32_t n = min(uniform(*in_cnt), a.hlist_cap);
 	if ((uint32_t) FIX_WG * blockIdx.x >= n)
 		return;
@@ -1136,6 +1129,7 @@ __global__ __launch_bounds__(256) void k_huff_tiles(DecodeArgs a)
 			nt = base < a.max_htiles ? a.max_htiles - base : 0;
 		a.hread[2 * r] = base;
 		a.hread[2 * r + 1] = nt;
+		a.hmin[r] = 0xFFFFFFFFu; // (k_huf_fix marks the reads its rounds leave unsettled)
 	}
 	// the descriptors: the wave writes the tiles of its 64 reads together, 64 tiles at a time (a lane per read
 	// wrote the 420 tiles of the longest read one after the other)
@@ -1183,13 +1177,8 @@ static void run_huff_decode(const DecodeArgs &a, hipStream_t s)
 	const uint32_t nge = (nt * (HT / 64) + WGE / 64 - 1) / (WGE / 64);
 	const uint32_t ge = nge < 2u * 256u ? nge : 2u * 256u;
 	hipLaunchKernelGGL((k_huf_sync<RU>), dim3(grid), dim3(WGS), 0, s, a);
-	hipLaunchKernelGGL(k_huf_tlinks, dim3((nt + 255) / 256), dim3(256), 0, s, a);
-	(void) hipMemsetAsync(a.hmin, 0xFF, (size_t) a.nreads * 4, s);
-	for (int round = 0; round < HUF_FIX_LAUNCHES; round++) {
-		// (the list this round fills: its count starts at zero)
-		(void) hipMemsetAsync(round & 1 ? &a.ctl->ticket2 : &a.ctl->list2, 0, 4, s);
+	for (int round = 0; round < HUF_FIX_LAUNCHES; round++)
 		hipLaunchKernelGGL((k_huf_fix<RU>), dim3(1280), dim3(FIX_WG), 0, s, a, round, round + 1 == HUF_FIX_LAUNCHES ? 1 : 0);
-	}
 	hipLaunchKernelGGL((k_huf_serial<RU>), dim3(a.nreads), dim3(64), 0, s, a);
 	hipLaunchKernelGGL(k_huf_chain, dim3(a.nreads), dim3(HT), 0, s, a);
 	hipLaunchKernelGGL((k_huf_emit<RU>), dim3(ge), dim3(WGE), 0, s, a); // (ctl->units: zero since the control block was cleared)

@@ -109,8 +109,7 @@ struct ChunkCtl {                           // device control block; every word 
 	uint32_t pad1[31];
 	uint32_t ticket2;   // spare second ticket
 	uint32_t pad2[31];  // (stays zero: k_low_decode_chunked loads its zeros from here)
-	uint32_t list2;     // Huffman decode: entries of the second repair list (the first list's: ticket2)
-	uint32_t pad3[31];
+	uint32_t lists[32]; // Huffman decode: entries of the list repair round r leaves (the first list's: ticket2)
 	uint32_t units;     // Huffman decode: next unit of work k_huf_emit hands out
 	uint32_t pad4[31];
 };
