@@ -1740,6 +1740,8 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 #ifdef DEC_STAMPS
 	const uint64_t t_start = __builtin_amdgcn_s_memtime();
 #endif
+	if (HUFF && uni(a.ctl->nchunks) == 0)
+		return; // (every read's samples were written by k_huf_emit: no tickets to draw)
 	for (;;) {
 	if (threadIdx.x == 0)
 		s_ticket = atomicAdd(&a.ctl->ticket, 1u);
