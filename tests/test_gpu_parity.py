@@ -466,6 +466,50 @@ def test_huffman_table_with_fewer_symbols(oracle, tmp_path):
         press.use_table()
 
 
+def test_huffman_table_that_never_synchronises(oracle, tmp_path):
+    """every code length a multiple of 3, subsequences of 128 bits: a decoder started off a code boundary
+    stays off it for ever, so two guesses in three are wrong and no repair round settles more than one
+    subsequence per read - the serial walk (k_huf_serial) has to deliver the whole read.  Byte parity with
+    the oracle and lossless, single reads and a batch"""
+    lens = [3] * 7 + [6] * 7 + [9] * 7 + [12] * 7 + [15] * 7 + [18] * 7 + [21] * 7 + [24] * 8  # Kraft sum 1
+    nsym = len(lens)
+    code, prev, bits = 0, lens[0], [0] * nsym
+    for sy in range(nsym):
+        code <<= lens[sy] - prev
+        prev = lens[sy]
+        bits[sy] = int(format(code, "0%db" % lens[sy])[::-1], 2)
+        code += 1
+    blob = bytearray(nsym.to_bytes(4, "big") + bytes(4))
+    for sy in range(nsym):
+        blob += bytes([sy, lens[sy]]) + bits[sy].to_bytes((lens[sy] + 7) // 8, "little")
+    path = str(tmp_path / "mult3.huffman")
+    open(path, "wb").write(bytes(blob))
+    rng = np.random.default_rng(33)
+    try:
+        oracle.load_table(path)
+        press.use_table(path)
+        sigs = []
+        for n in (2, 3, 50, 5000, 70000, 30011):
+            steps = rng.integers(-3, 4, size=n)
+            far = rng.random(n) < 0.05
+            steps[far] = rng.integers(-28, 29, size=int(far.sum()))  # zig-zag values up to 56: the long codes
+            steps[rng.random(n) < 0.002] += 300                      # a few exceptions
+            sigs.append(np.cumsum(steps).astype(np.int16))
+        sigs = [sig for sig in sigs if shuff_ok("shuffman_vbe21_zd", sig)]
+        assert len(sigs) >= 5
+        for m in ("shuffman_vbe21_zd", "shuffman_vbbe21_zd"):
+            for sig in sigs:
+                check_read(oracle, m, sig)
+            st = press.press_batch_host(m, sigs)
+            assert [x for x in st] == [oracle.press(m, sig)[1] for sig in sigs]
+            back = press.depress_batch_host(m, st, [len(sig) for sig in sigs])
+            for b, sig in zip(back, sigs):
+                assert np.array_equal(b, sig)
+    finally:
+        oracle.load_table()
+        press.use_table()
+
+
 def test_huffman_truncated_payload(oracle):
     """a Huffman stream cut short anywhere (tile boundaries included): the decoder delivers what
     the reference's huffman_decode_memory would - it stops when the bytes run out - and never
