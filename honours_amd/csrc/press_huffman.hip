@@ -926,7 +926,13 @@ __device__ __forceinline__ uint32_t zz_bytes(uint32_t d)
 }
 
 // two tiles side by side share the tables
-constexpr int WGE = 512; // eight waves, each on its own, share the tables
+#ifndef EMIT_WG
+#define EMIT_WG 512
+#endif
+#ifndef EMIT_PER_CU
+#define EMIT_PER_CU 2
+#endif
+constexpr int WGE = EMIT_WG; // eight waves, each on its own, share the tables
 constexpr uint32_t EMIT_UC = 16; // units of work a workgroup takes from the global counter at a time
 
 struct EmitStg { // the waves' staging buffers; emit_samples reads up to 8 bytes in front of / 12 behind a buffer's content
@@ -1177,7 +1183,7 @@ static void run_huff_decode(const DecodeArgs &a, hipStream_t s)
 	const uint32_t nt = a.max_htiles ? a.max_htiles : 1;
 	const uint32_t grid = (nt + 1) / 2 < 3u * 256u ? (nt + 1) / 2 : 3u * 256u;
 	const uint32_t nge = (nt * (HT / 64) + WGE / 64 - 1) / (WGE / 64);
-	const uint32_t ge = nge < 2u * 256u ? nge : 2u * 256u;
+	const uint32_t ge = nge < EMIT_PER_CU * 256u ? nge : EMIT_PER_CU * 256u;
 	hipLaunchKernelGGL((k_huf_sync<RU>), dim3(grid), dim3(WGS), 0, s, a);
 	for (int round = 0; round < HUF_FIX_LAUNCHES; round++)
 		hipLaunchKernelGGL((k_huf_fix<RU>), dim3(1280), dim3(FIX_WG), 0, s, a, round, round + 1 == HUF_FIX_LAUNCHES ? 1 : 0);

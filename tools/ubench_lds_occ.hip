@@ -15,6 +15,40 @@ __global__ void spin(unsigned long long ticks, unsigned *sink)
 		*sink = 1;
 }
 
+template <int LDS, int THR, bool BAR = true>
+__global__ __launch_bounds__(THR) void spin_static(unsigned long long ticks, unsigned *sink)
+{
+	__shared__ unsigned lds[LDS / 4];
+	for (int i = threadIdx.x; i < LDS / 4; i += THR)
+		lds[i] = i;
+	if (BAR)
+		__syncthreads();
+	const unsigned long long t0 = wall_clock64();
+	while (wall_clock64() - t0 < ticks)
+		;
+	if (lds[(threadIdx.x * 7) % (LDS / 4)] == 0xFFFFFFFFu)
+		*sink = 1;
+}
+
+template <int LDS, int THR, bool BAR = true>
+static void run_static(int m, unsigned long long ticks, unsigned *sink)
+{
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0);
+	hipEventCreate(&e1);
+	int occ = -1;
+	hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spin_static<LDS, THR, BAR>, THR, 0);
+	hipLaunchKernelGGL((spin_static<LDS, THR, BAR>), dim3(256 * m), dim3(THR), 0, 0, ticks, sink);
+	hipDeviceSynchronize();
+	hipEventRecord(e0, 0);
+	hipLaunchKernelGGL((spin_static<LDS, THR, BAR>), dim3(256 * m), dim3(THR), 0, 0, ticks, sink);
+	hipEventRecord(e1, 0);
+	hipDeviceSynchronize();
+	float ms = 0;
+	hipEventElapsedTime(&ms, e0, e1);
+	printf("static: threads %4d lds %6d barrier %d x%d per CU: %.2f ms, runtime says %d per CU (%s)\n", THR, LDS, (int) BAR, m, ms, occ, hipGetErrorString(hipGetLastError()));
+}
+
 int main()
 {
 	unsigned *sink;
@@ -40,5 +74,23 @@ int main()
 		hipEventElapsedTime(&ms, e0, e1);
 		printf("threads %4d lds %6d x%d per CU: %.2f ms (%s)\n", c.threads, c.lds, c.m, ms, hipGetErrorString(hipGetLastError()));
 	}
+	run_static<79392, 640>(2, ticks, sink);
+	run_static<73760, 576>(2, ticks, sink);
+	run_static<69920, 512>(2, ticks, sink);
+	run_static<65536, 640>(2, ticks, sink);
+	run_static<65024, 640>(2, ticks, sink);
+	run_static<60000, 640>(2, ticks, sink);
+	run_static<79392, 512>(2, ticks, sink);
+	run_static<79392, 640, false>(2, ticks, sink);
+	run_static<49204, 512>(3, ticks, sink);
+	run_static<49204, 512, false>(3, ticks, sink);
+	run_static<30000, 256>(5, ticks, sink);
+	run_static<30000, 256>(8, ticks, sink);
+	run_static<60000, 1024>(2, ticks, sink);
+	run_static<40000, 768>(2, ticks, sink);
+	run_static<40000, 384>(4, ticks, sink);
+	run_static<40000, 320>(4, ticks, sink);
+	run_static<50000, 320>(3, ticks, sink);
+	run_static<33000, 512>(4, ticks, sink);
 	return 0;
 }
