@@ -1205,17 +1205,26 @@ __global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
 			uint32_t hi = (z.x | z.y | z.z | z.w) & 0xFF00FF00u;
 			if (i0 == 0)
 				hi = ((z.x & 0xFF000000u) | ((z.y | z.z | z.w) & 0xFF00FF00u));
-			if (__ballot(hi != 0)) {
+			const bool anyex = __ballot(hi != 0) != 0;
+			if (anyex) {
 				kmask |= 1u << (kk + k);
 				const uint32_t inc = wave_incl_scan_dpp(__popc(exc_mask(z, i0)));
 				etot += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
 			}
 			if (HUFF) { // code lengths of the one-byte values: samples [1, n) that are no exceptions
-				const uint32_t lowm = low_mask(z, i0, n);
 				const uint32_t zz[4] = { z.x, z.y, z.z, z.w };
+				const uint32_t sub0 = ws + (kk + k) * SUB;
+				if (!anyex && sub0 != 0 && sub0 + SUB <= n) {
+					// a sub-tile of one-byte values only (nearly all are): no mask, no select per sample
 #pragma unroll
-				for (int h = 0; h < 8; h++) // (a lane sums 128 values of at most 24 bits: below 1 << 16)
-					lbits += s_len[((lowm >> h) & 1u) ? ((zz[h >> 1] >> (16 * (h & 1))) & 0xFFu) : 256u];
+					for (int h = 0; h < 8; h++)
+						lbits += s_len[(zz[h >> 1] >> (16 * (h & 1))) & 0xFFu];
+				} else {
+					const uint32_t lowm = low_mask(z, i0, n);
+#pragma unroll
+					for (int h = 0; h < 8; h++) // (a lane sums 128 values of at most 24 bits: below 1 << 16)
+						lbits += s_len[((lowm >> h) & 1u) ? ((zz[h >> 1] >> (16 * (h & 1))) & 0xFFu) : 256u];
+				}
 			}
 		}
 #pragma unroll
@@ -1530,14 +1539,23 @@ __global__ __launch_bounds__(CWG) void k_huff_encode_chunked(BatchArgs a)
 		const uint4 z = sub_zd(raw[0], n, i0, carry);
 		raw[0] = raw[1];
 		raw[1] = nxt;
-		const uint32_t lowm = low_mask(z, i0, n);
 		const uint32_t zz[4] = { z.x, z.y, z.z, z.w };
 		uint32_t e[8];
 		uint32_t lb = 0;
+		if (sub0 != 0 && sub0 + SUB <= n && !__ballot(((z.x | z.y | z.z | z.w) & 0xFF00FF00u) != 0)) {
+			// a sub-tile of one-byte values only (nearly all are): no mask, no select per sample
 #pragma unroll
-		for (int h = 0; h < 8; h++) {
-			e[h] = enc[((lowm >> h) & 1u) ? ((zz[h >> 1] >> (16 * (h & 1))) & 0xFFu) : 256u];
-			lb += e[h] >> 24;
+			for (int h = 0; h < 8; h++) {
+				e[h] = enc[(zz[h >> 1] >> (16 * (h & 1))) & 0xFFu];
+				lb += e[h] >> 24;
+			}
+		} else {
+			const uint32_t lowm = low_mask(z, i0, n);
+#pragma unroll
+			for (int h = 0; h < 8; h++) {
+				e[h] = enc[((lowm >> h) & 1u) ? ((zz[h >> 1] >> (16 * (h & 1))) & 0xFFu) : 256u];
+				lb += e[h] >> 24;
+			}
 		}
 		const uint32_t inc = wave_incl_scan_dpp(lb);
 		const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
