@@ -254,8 +254,15 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // ------------------------------------------------------------------ one tile
 
-// two tiles side by side share the tables (48 KiB of LDS per workgroup: three on a CU)
-constexpr int SG = 2;
+// four tiles side by side share the tables (74 KiB of LDS per 1024-thread workgroup, two on a CU: 8 waves per SIMD at
+// 64 VGPRs; two tiles per workgroup, three workgroups on a CU = 6 waves per SIMD: 5 % slower)
+#ifndef HUF_SG
+#define HUF_SG 4
+#endif
+#ifndef HUF_SYNC_PER_CU
+#define HUF_SYNC_PER_CU 2
+#endif
+constexpr int SG = HUF_SG;
 constexpr int WGS = SG * HT;
 constexpr int WGS_MAX = WGS;
 
@@ -409,7 +416,7 @@ __device__ __forceinline__ void load_len_tables(const HuffDev *hd, uint32_t *mlu
 
 // All tiles.  Persistent workgroups: the tables are loaded once.
 template <int RU>
-__global__ __launch_bounds__(WGS, 6) void k_huf_sync(DecodeArgs a)
+__global__ __launch_bounds__(WGS, HUF_SYNC_PER_CU * SG) void k_huf_sync(DecodeArgs a)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t lut[1 << HUF_LUT_BITS];
 	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
@@ -437,7 +444,10 @@ __global__ __launch_bounds__(WGS, 6) void k_huf_sync(DecodeArgs a)
 // ended.  If that moves the subsequence's own end, its right neighbour goes on the next round's list.  Lists:
 // a.hlist[0 .. cap) and a.hlist[cap .. 2 cap) take turns (`round` odd: the second is read), their counts in
 // ctl->ticket2 (what k_huf_sync listed) and ctl->lists[round] (what this round lists).  `last`: what is still pushed marks its read for k_huf_serial (a.hmin).
-constexpr int FIX_WG = 256; // four waves, each on its own, share the tables
+#ifndef HUF_FIX_WG
+#define HUF_FIX_WG 1024
+#endif
+constexpr int FIX_WG = HUF_FIX_WG; // waves that are each on their own share the tables
 template <int RU>
 __global__ __launch_bounds__(FIX_WG) void k_huf_fix(DecodeArgs a, int round, int last)
 {
@@ -1181,12 +1191,12 @@ static void run_huff_decode(const DecodeArgs &a, hipStream_t s)
 {
 	// persistent workgroups: what is resident (sync: 3 per CU, emit: 2, both of two tiles)
 	const uint32_t nt = a.max_htiles ? a.max_htiles : 1;
-	const uint32_t grid = (nt + 1) / 2 < 3u * 256u ? (nt + 1) / 2 : 3u * 256u;
+	const uint32_t grid = (nt + SG - 1) / SG < HUF_SYNC_PER_CU * 256u ? (nt + SG - 1) / SG : HUF_SYNC_PER_CU * 256u;
 	const uint32_t nge = (nt * (HT / 64) + WGE / 64 - 1) / (WGE / 64);
 	const uint32_t ge = nge < EMIT_PER_CU * 256u ? nge : EMIT_PER_CU * 256u;
 	hipLaunchKernelGGL((k_huf_sync<RU>), dim3(grid), dim3(WGS), 0, s, a);
 	for (int round = 0; round < HUF_FIX_LAUNCHES; round++)
-		hipLaunchKernelGGL((k_huf_fix<RU>), dim3(1280), dim3(FIX_WG), 0, s, a, round, round + 1 == HUF_FIX_LAUNCHES ? 1 : 0);
+		hipLaunchKernelGGL((k_huf_fix<RU>), dim3(FIX_WG >= 1024 ? 512 : FIX_WG >= 512 ? 768 : 1280), dim3(FIX_WG), 0, s, a, round, round + 1 == HUF_FIX_LAUNCHES ? 1 : 0);
 	hipLaunchKernelGGL((k_huf_serial<RU>), dim3(a.nreads), dim3(64), 0, s, a);
 	hipLaunchKernelGGL(k_huf_chain, dim3(a.nreads), dim3(HT), 0, s, a);
 	hipLaunchKernelGGL((k_huf_emit<RU>), dim3(ge), dim3(WGE), 0, s, a); // (ctl->units: zero since the control block was cleared)
