@@ -1140,8 +1140,17 @@ __global__ __launch_bounds__(256) void k_ex_redo_flag(BatchArgs a)
 // writes the (few) exceptions at their final rank from the flagged sub-tiles alone.
 // HUFF: also the number of Huffman code bits of every wave quarter (ChunkBits), which lets
 // k_huff_encode_chunked place its bits without any chain either.
+// Waves per SIMD the register allocator is asked to leave room for (measured: pass A is slower at 8 - a spill -,
+// the Huffman encoder 16 % faster - 38 instead of 76 registers; the svb and one-byte kernels are slower with any
+// hint: they stream, and the registers hold their loads in flight).
+#ifndef SCAN_WAVES
+#define SCAN_WAVES 4
+#endif
+#ifndef HENC_WAVES
+#define HENC_WAVES 8
+#endif
 template <bool REDO, bool HUFF = false>
-__global__ __launch_bounds__(CWG) void k_ex_scan_chunked(BatchArgs a)
+__global__ __launch_bounds__(CWG, SCAN_WAVES) void k_ex_scan_chunked(BatchArgs a)
 {
 	// code length of every one-byte value, 1 << 16 for a value without a code; [256] = 0: what a sample that
 	// is no one-byte value (exception, sample 0, outside the read) looks up
@@ -1464,7 +1473,7 @@ __device__ __forceinline__ uint32_t huff_tail_bits(const int16_t *in, uint32_t e
 }
 
 
-__global__ __launch_bounds__(CWG) void k_huff_encode_chunked(BatchArgs a)
+__global__ __launch_bounds__(CWG, HENC_WAVES) void k_huff_encode_chunked(BatchArgs a)
 {
 	__shared__ uint32_t enc[257]; // [256] = 0: what a sample without a code (exception, outside the read) looks up
 	__shared__ uint32_t stg_all[4][HSTG];
