@@ -510,6 +510,18 @@ def test_huffman_table_that_never_synchronises(oracle, tmp_path):
         press.use_table()
 
 
+def test_huffman_batches_repeat_bit_for_bit():
+    """the Huffman batch kernels hand out work by tickets and build their repair lists with atomics: whatever the
+    order, every run of a batch gives the same streams and the samples back (tools/stress_huff.py, a few batches of
+    up to 200 reads, natural and fixed lengths, both exception formats, six runs each)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "stress_huff", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "stress_huff.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.stress(5, 200, repeat=4, verbose=False) == 5
+
+
 def test_huffman_truncated_payload(oracle):
     """a Huffman stream cut short anywhere (tile boundaries included): the decoder delivers what
     the reference's huffman_decode_memory would - it stops when the bytes run out - and never
