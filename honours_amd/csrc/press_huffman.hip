@@ -935,7 +935,8 @@ __device__ __forceinline__ uint32_t zz_bytes(uint32_t d)
 	return ((d << 1) & 0xFEFEFEFEu) ^ (((d >> 7) & 0x01010101u) * 0xFFu);
 }
 
-// two tiles side by side share the tables
+// eight waves share the tables (workgroup sizes that are no multiple of 256 threads do not run two to a CU on this
+// GPU whatever their registers and LDS: tools/ubench_lds_occ.hip)
 #ifndef EMIT_WG
 #define EMIT_WG 512
 #endif
@@ -1189,7 +1190,7 @@ constexpr int HUF_FIX_LAUNCHES = 4; // rounds of k_huf_fix (an ordinary table is
 template <int RU>
 static void run_huff_decode(const DecodeArgs &a, hipStream_t s)
 {
-	// persistent workgroups: what is resident (sync: 3 per CU, emit: 2, both of two tiles)
+	// persistent workgroups: what is resident (sync: 2 per CU of four tiles each, emit: 2 of eight waves)
 	const uint32_t nt = a.max_htiles ? a.max_htiles : 1;
 	const uint32_t grid = (nt + SG - 1) / SG < HUF_SYNC_PER_CU * 256u ? (nt + SG - 1) / SG : HUF_SYNC_PER_CU * 256u;
 	const uint32_t nge = (nt * (HT / 64) + WGE / 64 - 1) / (WGE / 64);

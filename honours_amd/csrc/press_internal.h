@@ -66,16 +66,14 @@ constexpr uint32_t HUF_M_MAXN = 8; // 8 deltas of -128 .. 127 fit the 11-bit sum
 constexpr uint32_t HUF_LONG = 1u << 30;
 constexpr uint32_t HUF_TWO = 1u << 29;
 
-// parallel Huffman decode (press_huffman.hip): tiles of HUF_HT subsequences, one workgroup each
-constexpr int HUF_HT = 256;        // threads per workgroup = subsequences per tile
-struct HufTRec {             // what k_huf_sync leaves per tile (32 bytes)
-	uint32_t se;         // start it assumed | where the next tile's first code starts << 8 (0 .. 30, 31 = none)
-	uint32_t count;      // codes that start in the tile
-	uint32_t base;       // codes of the read in front of the tile (k_huf_chain)
-	uint32_t dbase;      // sum of their deltas, mod 2^16 (k_huf_chain)
-	uint16_t wd[4];      // sum of the deltas of the codes of each wave's 64 subsequences, mod 2^16
-	uint32_t dtot;       // ... of the tile
-	uint32_t fused;      // k_huf_chain: 1 = k_huf_emit writes the read's samples itself, 0 = its one-byte
+// parallel Huffman decode (press_huffman.hip): tiles of HUF_HT subsequences
+constexpr int HUF_HT = 256;        // subsequences per tile (a lane each)
+struct HufTRec {             // what k_huf_chain leaves per tile (32 bytes: k_huf_emit takes it in two 16-byte loads)
+	uint32_t rsv0[2];
+	uint32_t base;       // codes of the read in front of the tile
+	uint32_t dbase;      // sum of their deltas, mod 2^16
+	uint32_t rsv1[3];
+	uint32_t fused;      // 1 = k_huf_emit writes the read's samples itself, 0 = its one-byte
 	                     // values go to DecodeArgs::low and k_low_decode_chunked merges them
 };
 static_assert(sizeof(HufTRec) == 32, "HufTRec");
