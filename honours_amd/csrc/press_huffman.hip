@@ -103,7 +103,7 @@ __device__ __forceinline__ uint32_t clamp_nb(int64_t v)
 // run-up of a tile's first lane lies in the previous tile) into a column.  Bytes outside
 // the payload [lo, nby) read as zero.  Lanes whose dwords all lie inside issue their loads back
 // to back (16-byte loads at any byte address).
-template <int NDW>
+template <int NDW, int S = 64>
 __device__ __forceinline__ void col_load(uint32_t *col, const uint8_t *src, int32_t rb0, int32_t lo, int32_t nby)
 {
 	if (rb0 >= lo && rb0 + 4 * NDW <= nby) {
@@ -118,14 +118,14 @@ __device__ __forceinline__ void col_load(uint32_t *col, const uint8_t *src, int3
 			__builtin_memcpy(&x[j], q + 4 * (NDW / 4 * 4 + j), 4);
 #pragma unroll
 		for (int j = 0; j < NDW / 4; j++) {
-			col[(4 * j + 0) * 64] = t[j].x;
-			col[(4 * j + 1) * 64] = t[j].y;
-			col[(4 * j + 2) * 64] = t[j].z;
-			col[(4 * j + 3) * 64] = t[j].w;
+			col[(4 * j + 0) * S] = t[j].x;
+			col[(4 * j + 1) * S] = t[j].y;
+			col[(4 * j + 2) * S] = t[j].z;
+			col[(4 * j + 3) * S] = t[j].w;
 		}
 #pragma unroll
 		for (int j = 0; j < NDW % 4; j++)
-			col[(NDW / 4 * 4 + j) * 64] = x[j];
+			col[(NDW / 4 * 4 + j) * S] = x[j];
 	} else {
 		for (int j = 0; j < NDW; j++) { // rolled: the ends of a payload only
 			const int32_t r = rb0 + 4 * j;
@@ -135,7 +135,7 @@ __device__ __forceinline__ void col_load(uint32_t *col, const uint8_t *src, int3
 					if (r + i >= lo && r + i < nby)
 						x |= (uint32_t) src[r + i] << (8 * i);
 			}
-			col[j * 64] = x;
+			col[j * S] = x;
 		}
 	}
 }
@@ -149,6 +149,7 @@ __device__ __forceinline__ int32_t unzz8(uint32_t z) { return (int32_t) (z >> 1)
 // mlut entry (HuffDev::mlut): total bits | codes << 4 | bits of the first code << 8 | its delta << 12 |
 // sum of the deltas << 20 of every whole code that fits in 12 bits; long codes (13 .. 24 bits: one code
 // in 200 of the NA12878 table, one look-up in four has such a lane) through the second-level table.
+template <int S = 64>
 __device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint32_t *mlut, const uint16_t *l2ld,
 					     const HuffDev *hd, uint32_t start, uint32_t lim, uint32_t nb, uint32_t &cnt,
 					     uint32_t &dsum)
@@ -172,13 +173,13 @@ __device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint32_t
 	{
 		int32_t Lm = (int32_t) L - HUF_LUT_BITS; // every code of a look-up starts below L while p <= Lm
 		uint32_t j = p >> 5;
-		uint32_t w0 = col[j * 64], w1 = col[(j + 1) * 64];
+		uint32_t w0 = col[j * S], w1 = col[(j + 1) * S];
 		for (;;) {
 			const bool act = (int32_t) p <= Lm;
 			if (!any64(act))
 				break;
 			if (act) { // (exec-masked body: the lanes that are done do nothing)
-				const uint32_t w2 = col[(j + 2) * 64]; // (the row behind the last column keeps this read inside the array)
+				const uint32_t w2 = col[(j + 2) * S]; // (the row behind the last column keeps this read inside the array)
 				const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p); // shift = p & 31
 				const uint32_t e = mlut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
 				uint32_t tot = e & 15u, n = (e >> 4) & 15u;
@@ -212,7 +213,7 @@ __device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint32_t
 			break;
 		const uint32_t pp = act ? p : 0u;
 		const uint32_t j = pp >> 5;
-		const uint32_t wnd = __builtin_amdgcn_alignbit(col[(j + 1) * 64], col[j * 64], pp);
+		const uint32_t wnd = __builtin_amdgcn_alignbit(col[(j + 1) * S], col[j * S], pp);
 		const uint32_t e = mlut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
 		uint32_t tot = e & 15u, n = (e >> 4) & 15u, len1 = (e >> 8) & 15u;
 		int32_t dall = (int32_t) (e << 1) >> 21, d1 = (int32_t) (e << 12) >> 24;
@@ -254,27 +255,17 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // ------------------------------------------------------------------ one tile
 
-// four tiles side by side share the tables (74 KiB of LDS per 1024-thread workgroup, two on a CU: 8 waves per SIMD at
-// 64 VGPRs; two tiles per workgroup, three workgroups on a CU = 6 waves per SIMD: 5 % slower)
-#ifndef HUF_SG
-#define HUF_SG 4
-#endif
+// ------------------------------------------------------------------ first pass
+
+// Sixteen waves share the tables and nothing else: a wave takes a quarter of a tile (64 subsequences) per ticket and
+// never meets the workgroup's other waves at a barrier, so that the waves of a CU are in different phases - loads,
+// run-up, own pass, records - at any time (with the four barriers per round of the tile-per-256-threads version the
+// sixteen waves of a workgroup waited for the round's loads together: 0.82 ms for 0.62 ms of instruction issue).
 #ifndef HUF_SYNC_PER_CU
 #define HUF_SYNC_PER_CU 2
 #endif
-constexpr int SG = HUF_SG;
-constexpr int WGS = SG * HT;
-constexpr int WGS_MAX = WGS;
-
-template <int RU>
-struct TileLds { // what a workgroup keeps per tile besides the tables
-	static constexpr int NCOL = HufGeo<RU>::NCOL;
-	// column of lane l of wave w: img[w + 1] + l; img[0] + 63 = the last subsequence of the tile in front;
-	// one row behind the last column for len_scan's prefetch
-	uint32_t img[HT / 64 + 1][NCOL * 64];
-	uint32_t pad_row[64];
-	uint8_t s_e[HT];
-};
+constexpr int WGS = 1024;
+constexpr int SYNC_S = 65; // dwords per row of a wave's image: 64 lanes and, in front, the subsequence before the first
 
 // what k_huf_sync / k_huf_fix leave per subsequence: a.hrec = start | codes << 8 | sum of their deltas << 16,
 // a.hend = where the next subsequence's first code starts (0 .. 30, R_END: none)
@@ -284,7 +275,8 @@ __device__ __forceinline__ uint32_t pack_rec(uint32_t f, uint32_t c, uint32_t d)
 }
 
 constexpr uint32_t LIST_NONE = 0xFFFFFFFFu; // an unused list slot
-constexpr uint32_t LIST_CHUNK = 1024;       // slots a workgroup of k_huf_sync takes from the list at a time
+constexpr uint32_t LIST_CHUNK = 128;        // slots a wave of k_huf_sync takes from the list at a time
+constexpr uint32_t SYNC_UC = 16;            // quarter tiles a workgroup takes from the global counter at a time
 
 // append the lanes with `yes` to the list whose counter is *cnt (one atomic per wave)
 __device__ __forceinline__ void list_push(uint32_t *list, uint32_t *cnt, uint32_t cap, bool yes, uint32_t value, uint32_t lane)
@@ -301,106 +293,6 @@ __device__ __forceinline__ void list_push(uint32_t *list, uint32_t *cnt, uint32_
 		list[idx] = value;
 }
 
-// Tile k, first pass, by the 256 threads of group `grp` of the workgroup (the G groups of a workgroup run
-// their tiles side by side and share the barriers; has = false: a group without a tile only keeps them): every
-// lane runs up through the half subsequence in front of its own - where that crosses into its subsequence is its
-// guess of the first code's start - and then through its own.  Lanes whose guess is not where the left neighbour
-// ended go on the list of k_huf_fix; nothing is repaired here (while one wave decoded a tile's two or three such
-// lanes again, the other seven of the workgroup waited: a quarter of this kernel's time).
-struct SyncList { // a workgroup's place in the list of k_huf_fix (LDS)
-	uint32_t pos, end;       // its current chunk: next free slot, end
-	uint32_t wcnt[WGS_MAX / 64]; // this round: entries of every wave
-	uint32_t old, rem, nbase; // ... and where they go: `rem` into the old chunk from `old`, the rest from `nbase`
-};
-
-template <int RU, int G>
-__device__ __forceinline__ void sync_tile(const DecodeArgs &a, uint32_t k, bool has, TileLds<RU> *TT,
-					  const uint32_t *lut, const uint16_t *lut2, SyncList &SL)
-{
-	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW;
-	const uint32_t grp = G > 1 ? uniform(threadIdx.x >> 8) : 0u;
-	TileLds<RU> &T = TT[grp];
-	const uint32_t tid = threadIdx.x & (HT - 1);
-	const uint32_t lane = tid & 63;
-	const HufTile *dp = a.htiles + k;
-	const uint32_t nbits_t = has ? uniform(dp->nbits) : 0u;
-	const uint32_t t = uniform(dp->t_last) & 0x7FFFFFFFu;
-	const uint8_t *src = a.in + dp->src;
-	const int32_t nby = (int32_t) ((nbits_t + 7) >> 3); // (nbits_t < 2^32: below 2^29 bytes)
-	uint32_t *col = T.img[(tid >> 6) + 1] + lane;
-	const uint32_t *rcol = T.img[(tid + 63) >> 6] + ((tid + 63) & 63); // the left neighbour's column
-	const bool exact = t == 0; // the first lane's start is known: the read's payload starts here
-
-	col_load<NDW>(col, src, (int32_t) tid * (OWN / 8), 0, nby);
-	if (tid == 0 && !exact) // the bits in front of the tile belong to the same payload
-		col_load<NDW>(T.img[0] + 63, src, -(OWN / 8), -(OWN / 8), nby);
-	__syncthreads(); // columns (a lane's run-up reads its neighbour's)
-	// payload end in the coordinates of the own / the neighbour's column
-	const uint32_t nb = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN);
-	const uint32_t nbr = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN + OWN);
-
-	// ---- run-up through the second half of the subsequence in front, then the own one
-	const bool first_known = tid == 0 && exact;
-	uint32_t f, c0, c, dz, dv;
-	{
-		const uint32_t g = len_scan(rcol, lut, lut2, a.huff, first_known ? HEND : (uint32_t) RU, OWN, nbr, c0, dz);
-		f = g == HEND ? HEND : g - OWN;
-		if (g == HEND && nb > 0)
-			f = 0; // the guess ran into a bit pattern that is no code: any guess will do
-		if (first_known)
-			f = 0;
-	}
-	const uint32_t e = len_scan(col, lut, lut2, a.huff, f, OWN, nb, c, dv);
-	const uint32_t e8 = e == HEND ? R_END : e - OWN;
-	T.s_e[tid] = (uint8_t) e8;
-	const uint32_t cw = wave_scan(c), dw = wave_scan(dv);
-	if (has) {
-		a.hrec[(uint64_t) k * HT + tid] = pack_rec(f, c, dv);
-		a.hend[(uint64_t) k * HT + tid] = (uint8_t) e8;
-		if (lane == 63) // the wave's totals (k_huf_fix adds what its repairs change)
-			a.hwave[(uint64_t) k * (HT / 64) + (tid >> 6)] = make_uint2(cw, dw & 0xFFFFu);
-	}
-	__syncthreads(); // the neighbours' ends; the columns are free again behind this
-	// (the first lane of a tile: against the tile in front if that is the workgroup's other tile; else listed
-	// unchecked - k_huf_fix then starts it from where the tile in front ended, which is only known after this kernel)
-	const uint32_t f8 = f == HEND ? R_END : f;
-	bool broken = has && tid > 0 && f8 != T.s_e[tid - 1];
-	if (tid == 0 && has && !exact)
-		broken = (G > 1 && grp > 0) ? f8 != TT[grp - 1].s_e[HT - 1] : true;
-	// ---- the workgroup's broken lanes go to its chunk of the list: one global atomic per LIST_CHUNK entries
-	// (an atomic per wave - 400 000 on one counter - tripled this kernel's time)
-	const unsigned long long bm = __ballot(broken);
-	const uint32_t wv = threadIdx.x >> 6;
-	if ((threadIdx.x & 63) == 0)
-		SL.wcnt[wv] = (uint32_t) __popcll(bm);
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint32_t tot = 0;
-		for (uint32_t w2 = 0; w2 < (uint32_t) (G * HT / 64); w2++)
-			tot += SL.wcnt[w2];
-		const uint32_t rem = SL.end - SL.pos;
-		SL.old = SL.pos;
-		SL.rem = rem;
-		if (tot > rem) { // (tot <= the workgroup's threads <= LIST_CHUNK)
-			const uint32_t nbase = atomicAdd(&a.ctl->ticket2, LIST_CHUNK);
-			SL.nbase = nbase;
-			SL.pos = nbase + (tot - rem);
-			SL.end = nbase + LIST_CHUNK;
-		} else {
-			SL.pos += tot;
-		}
-	}
-	__syncthreads();
-	if (broken) {
-		uint32_t j = (uint32_t) __popcll(bm & ((1ull << lane) - 1ull));
-		for (uint32_t w2 = 0; w2 < wv; w2++)
-			j += SL.wcnt[w2];
-		const uint32_t idx = j < SL.rem ? SL.old + j : SL.nbase + (j - SL.rem);
-		if (idx < a.hlist_cap)
-			a.hlist[idx] = k * HT + tid;
-	}
-}
-
 __device__ __forceinline__ void load_len_tables(const HuffDev *hd, uint32_t *mlut, uint16_t *l2ld, uint32_t nthr)
 {
 	const uint4 *s4 = reinterpret_cast<const uint4 *>(hd->mlut);
@@ -414,29 +306,124 @@ __device__ __forceinline__ void load_len_tables(const HuffDev *hd, uint32_t *mlu
 }
 
 
-// All tiles.  Persistent workgroups: the tables are loaded once.
+// All tiles, first pass.  Persistent workgroups (the tables are loaded once); a wave's unit of work is a quarter of
+// a tile: every lane runs up through the half subsequence in front of its own - where that crosses into its
+// subsequence is its guess of the first code's start - and then through its own.  Lanes whose guess is not where the
+// left neighbour ended go on the list of k_huf_fix, and so does every unit's first lane, unchecked: where the
+// subsequence in front of it ended another wave knows (k_huf_fix drops the entry if the guess was right).  Nothing
+// is repaired here.  Units are drawn from a ticket (as in k_huf_emit); list slots are taken LIST_CHUNK at a time
+// per wave (an atomic per push - 400 000 on one counter - tripled this kernel's time), unused ones hold LIST_NONE.
 template <int RU>
-__global__ __launch_bounds__(WGS, HUF_SYNC_PER_CU * SG) void k_huf_sync(DecodeArgs a)
+__global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(DecodeArgs a)
 {
+	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW;
+	constexpr int S = SYNC_S;
 	__shared__ __attribute__((aligned(16))) uint32_t lut[1 << HUF_LUT_BITS];
 	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
-	__shared__ TileLds<RU> T[SG];
-	__shared__ SyncList SL;
+	// a wave's image: row j = dword j of [the subsequence in front, lane 0 .. lane 63]; two rows behind the last for
+	// len_scan's look-ahead
+	__shared__ uint32_t imgs[WGS / 64][(NDW + 2) * S];
+	__shared__ unsigned long long s_chunk[64];
+	__shared__ uint32_t s_ticket;
 
 	const uint32_t n = min(uniform(a.ctl->nchunks), a.max_htiles);
-	if (SG * blockIdx.x >= n)
-		return;
-	const uint32_t grp = uniform(threadIdx.x >> 8);
+	const uint32_t nunits = n * (HT / 64);
+	const uint32_t lane = threadIdx.x & 63;
 	if (threadIdx.x == 0)
-		SL.pos = SL.end = 0;
+		s_ticket = 0;
+	if (threadIdx.x < 64)
+		s_chunk[threadIdx.x] = ~0ull;
 	load_len_tables(a.huff, lut, lut2, WGS);
-	for (uint32_t i0 = SG * blockIdx.x; i0 < n; i0 += SG * gridDim.x) {
-		const uint32_t i = i0 + grp;
-		const bool has = i < n; // (an odd count leaves the last group idle)
-		sync_tile<RU, SG>(a, has ? i : i0, has, T, lut, lut2, SL);
+	__syncthreads(); // the tables: the only barrier
+	uint32_t *img = imgs[threadIdx.x >> 6];
+	for (uint32_t i = lane; i < 2 * S; i += 64)
+		img[NDW * S + i] = 0;
+	uint32_t *col = img + 1 + lane;
+	const uint32_t *rcol = img + lane; // the left neighbour's column
+	uint32_t lpos = 0, lend = 0;       // the wave's chunk of the list: next free slot, end
+	for (;;) {
+		uint32_t u = 0;
+		if (lane == 0) {
+			const uint32_t t = atomicAdd(&s_ticket, 1u);
+			const uint32_t c = t / SYNC_UC, slot = t % SYNC_UC;
+			unsigned long long *cs = &s_chunk[c & 63u];
+			if (slot == 0) {
+				u = atomicAdd(&a.ctl->sunits, SYNC_UC);
+				__hip_atomic_store(cs, ((unsigned long long) c << 32) | u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			} else {
+				unsigned long long v;
+				do {
+					v = __hip_atomic_load(cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				} while ((uint32_t) (v >> 32) != c);
+				u = (uint32_t) v + slot;
+			}
+		}
+		u = uniform(u);
+		if (u >= nunits)
+			break;
+		const uint32_t k = u / (HT / 64);
+		const uint32_t tid = (u % (HT / 64)) * 64 + lane; // the lane's subsequence of the tile
+		const HufTile *dp = a.htiles + k;
+		const uint32_t nbits_t = uniform(dp->nbits);
+		const uint32_t t = uniform(dp->t_last) & 0x7FFFFFFFu;
+		const uint8_t *src = a.in + dp->src;
+		const int32_t nby = (int32_t) ((nbits_t + 7) >> 3); // (nbits_t < 2^32: below 2^29 bytes)
+		const bool exact = t == 0 && tid < 64; // the unit's first lane starts the read's payload: its start is known
+
+		wave_lds_sync(); // (the image is free: the last unit's scans are through)
+		col_load<NDW, S>(col, src, (int32_t) tid * (OWN / 8), 0, nby);
+		if (lane == 0 && !exact) // the bits in front of the unit belong to the same payload (maybe to the tile in front)
+			col_load<NDW, S>(img, src, (int32_t) tid * (OWN / 8) - (OWN / 8), tid ? 0 : -(OWN / 8), nby);
+		wave_lds_sync(); // columns (a lane's run-up reads its neighbour's)
+		// payload end in the coordinates of the own / the neighbour's column
+		const uint32_t nb = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN);
+		const uint32_t nbr = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN + OWN);
+
+		// ---- run-up through the second half of the subsequence in front, then the own one
+		const bool first_known = lane == 0 && exact;
+		uint32_t f, c0, c, dz, dv;
+		{
+			const uint32_t g = len_scan<S>(rcol, lut, lut2, a.huff, first_known ? HEND : (uint32_t) RU, OWN, nbr, c0, dz);
+			f = g == HEND ? HEND : g - OWN;
+			if (g == HEND && nb > 0)
+				f = 0; // the guess ran into a bit pattern that is no code: any guess will do
+			if (first_known)
+				f = 0;
+		}
+		const uint32_t e = len_scan<S>(col, lut, lut2, a.huff, f, OWN, nb, c, dv);
+		const uint32_t e8 = e == HEND ? R_END : e - OWN;
+		const uint32_t cw = wave_scan(c), dw = wave_scan(dv);
+		a.hrec[(uint64_t) k * HT + tid] = pack_rec(f, c, dv);
+		a.hend[(uint64_t) k * HT + tid] = (uint8_t) e8;
+		if (lane == 63) // the wave's totals (k_huf_fix adds what its repairs change)
+			a.hwave[u] = make_uint2(cw, dw & 0xFFFFu);
+		// ---- whose guess is not where the neighbour ended
+		const uint32_t f8 = f == HEND ? R_END : f;
+		const uint32_t pe8 = (uint32_t) __shfl_up((int) e8, 1, 64);
+		const bool broken = lane ? f8 != pe8 : !exact;
+		const unsigned long long bm = __ballot(broken);
+		if (bm) {
+			const uint32_t cnt = (uint32_t) __popcll(bm);
+			const uint32_t rem = lend - lpos, old_pos = lpos;
+			uint32_t nbase = 0;
+			if (cnt > rem) { // (cnt <= 64 <= LIST_CHUNK)
+				if (lane == 0)
+					nbase = atomicAdd(&a.ctl->ticket2, LIST_CHUNK);
+				nbase = uniform(nbase);
+				lpos = nbase + (cnt - rem);
+				lend = nbase + LIST_CHUNK;
+			} else {
+				lpos += cnt;
+			}
+			if (broken) {
+				const uint32_t j = (uint32_t) __popcll(bm & ((1ull << lane) - 1ull));
+				const uint32_t idx = j < rem ? old_pos + j : nbase + (j - rem);
+				if (idx < a.hlist_cap)
+					a.hlist[idx] = k * HT + tid;
+			}
+		}
 	}
-	__syncthreads();
-	for (uint32_t j = SL.pos + threadIdx.x; j < SL.end && j < a.hlist_cap; j += WGS) // what is left of the last chunk
+	for (uint32_t j = lpos + lane; j < lend && j < a.hlist_cap; j += 64) // what is left of the wave's last chunk
 		a.hlist[j] = LIST_NONE;
 }
 
@@ -468,6 +455,10 @@ __global__ __launch_bounds__(FIX_WG) void k_huf_fix(DecodeArgs a, int round, int
 	uint32_t *col = imgs[threadIdx.x >> 6] + lane;
 	for (uint32_t i0 = FIX_WG * blockIdx.x + (threadIdx.x & ~63u); i0 < n; i0 += (uint32_t) FIX_WG * gridDim.x) {
 		uint32_t ent = i0 + lane < n ? in_list[i0 + lane] : LIST_NONE;
+		// (k_huf_sync lists the first lane of every quarter tile unchecked: most of them started where the
+		// subsequence in front ended - nothing to do)
+		if (ent != LIST_NONE && (a.hrec[ent] & 0xFFu) == a.hend[ent - 1])
+			ent = LIST_NONE;
 		const bool mine = ent != LIST_NONE;
 		const uint64_t g = mine ? ent : 1u;
 		const uint32_t k = (uint32_t) (g / HT), tid = (uint32_t) (g % HT);
@@ -1192,7 +1183,8 @@ static void run_huff_decode(const DecodeArgs &a, hipStream_t s)
 {
 	// persistent workgroups: what is resident (sync: 2 per CU of four tiles each, emit: 2 of eight waves)
 	const uint32_t nt = a.max_htiles ? a.max_htiles : 1;
-	const uint32_t grid = (nt + SG - 1) / SG < HUF_SYNC_PER_CU * 256u ? (nt + SG - 1) / SG : HUF_SYNC_PER_CU * 256u;
+	const uint32_t ngs = (nt * (HT / 64) + WGS / 64 - 1) / (WGS / 64);
+	const uint32_t grid = ngs < HUF_SYNC_PER_CU * 256u ? ngs : HUF_SYNC_PER_CU * 256u;
 	const uint32_t nge = (nt * (HT / 64) + WGE / 64 - 1) / (WGE / 64);
 	const uint32_t ge = nge < EMIT_PER_CU * 256u ? nge : EMIT_PER_CU * 256u;
 	hipLaunchKernelGGL((k_huf_sync<RU>), dim3(grid), dim3(WGS), 0, s, a);

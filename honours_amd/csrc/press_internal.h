@@ -110,6 +110,8 @@ struct ChunkCtl {                           // device control block; every word 
 	uint32_t lists[32]; // Huffman decode: entries of the list repair round r leaves (the first list's: ticket2)
 	uint32_t units;     // Huffman decode: next unit of work k_huf_emit hands out
 	uint32_t pad4[31];
+	uint32_t sunits;    // ... and k_huf_sync
+	uint32_t pad5[31];
 };
 
 // Arguments common to every batch kernel.
