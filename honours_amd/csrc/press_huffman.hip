@@ -3,8 +3,9 @@
 // The stream has no synchronisation points, but Huffman codes self-synchronise: a decoder
 // started at a wrong bit position falls back onto true code boundaries after a few codes.
 // The payload of every read is cut into SUBSEQUENCES of OWN bits (256 for the NA12878 table,
-// whose shortest code has 4 bits), one lane each; a TILE = 256 subsequences (8 KiB), two of them side by
-// side in a 512-thread workgroup that shares the tables.  Nothing in the two heavy kernels waits for another tile:
+// whose shortest code has 4 bits), one lane each; a TILE = 256 subsequences (8 KiB) is the unit the records are
+// kept by, a quarter of it (64 subsequences) what a wave takes at a time.  In the two heavy kernels the waves of a
+// workgroup share the tables and nothing else - no barrier, no wave waits for another:
 //
 //   k_huf_sync   where do codes start?  Lengths (and the sample deltas the symbols stand for - no symbols): one
 //                LDS look-up takes every whole code that fits in 12 bits.  Lane i runs through the RU = OWN/2 bits in front of its subsequence from
@@ -13,9 +14,11 @@
 //                Leaves a record per subsequence {start, codes, sum of their deltas}, where it ended, and
 //                per wave of a tile the totals; lanes whose guess is not where the left neighbour ended
 //                (~3 %) go on a list - nothing is repaired here (a wave repairing the tile's two or three such
-//                lanes while seven others waited at the barrier was a quarter of this kernel).
-//                The lane's bits live in a private LDS column (dword j of lane l at j*64 + l: any mix
-//                of per-lane positions is bank-conflict free); a lane's run-up reads its neighbour's.
+//                lanes while seven others waited at the barrier was a quarter of this kernel) - and so does the
+//                first lane of every quarter, unchecked (its left neighbour is another wave's).
+//                The lane's bits live in a private LDS column (dword j of lane l at j*65 + l + 1; in
+//                k_huf_emit at j*64 + l: any mix of per-lane positions is bank-conflict free); a lane's run-up
+//                reads its neighbour's, the first lane's the column the wave loads in front of its 64.
 //                The loops are wave-uniform with predicated bodies; while 12 bits are left in front of
 //                the limit nothing can step over it, so the body is one look-up fed from a register
 //                window over the column (the dword behind the window is fetched while the look-up is in
