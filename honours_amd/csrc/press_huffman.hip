@@ -923,6 +923,90 @@ __device__ __forceinline__ void emit_samples(const uint8_t *src, const EmitRead 
 	}
 }
 
+// The same from the LDS staging buffer with 16 samples per lane and round (1024 per round): half the wave scans
+// and half the rounds of emit_samples; a lane's two groups of 8 are what emit_samples gives two lanes.
+__device__ __forceinline__ void emit_samples16(const uint8_t *src, const EmitRead &R, const EmitPlan &P, uint32_t lane)
+{
+	const uint32_t L0 = P.L0, L1 = P.L1, Ea = P.Ea, ecnt = P.ecnt, Ia = P.Ia, Ib = P.Ib, pe = P.pe;
+	uint32_t base = P.base;
+	auto ex_below = [&](uint32_t key) -> uint32_t { // exceptions of the wave with pos < key
+		if (ecnt == 0)
+			return 0u;
+		if (ecnt <= 64)
+			return (uint32_t) __popcll(__ballot(pe < key));
+		return uniform(lower_bound_u32(R.pos + Ea, ecnt, key));
+	};
+	const bool shift = uniform(R.q) != 0;
+	const u16x2 qq = { (unsigned short) R.q, (unsigned short) R.q };
+	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
+	for (uint32_t g = Ia & ~(EMIT_ALIGN - 1); g < Ib; g += 1024) {
+		const uint32_t i0 = g + lane * 16;
+		// exceptions in front of sample g / of sample g + 1024
+		const uint32_t e0 = ex_below(g ? g - 1 : 0u), e1 = ex_below(g + 1023);
+		const bool plain = e0 == e1 && g != 0;
+		const bool ragged = g < Ia || g + 1024 > Ib;
+		uint32_t v[8];
+		if (plain) {
+			// sample i = value number i - 1 - (Ea + e0)
+			const bool any = i0 + 16 > Ia && i0 < Ib;
+			const int32_t o = any ? (int32_t) (i0 - 1 - Ea - e0 - L0) : 0; // >= -16 (the staging buffers have room in front)
+			const int32_t j = o >> 2;
+			const uint32_t sh = (uint32_t) (o & 3) * 8u; // (the same in every lane)
+			const uint32_t d0 = s32[j], d1 = s32[j + 1], d2 = s32[j + 2], d3 = s32[j + 3], d4 = s32[j + 4];
+			uint2 da = make_uint2(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh));
+			uint2 db = make_uint2(__builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh));
+			if (ragged) {
+				auto mask8 = [&](uint2 &dd, uint32_t ia) {
+					const uint32_t lo = Ia > ia ? (Ia - ia < 8 ? Ia - ia : 8u) : 0u;
+					const uint32_t hi = Ib > ia ? (Ib - ia < 8 ? Ib - ia : 8u) : 0u;
+					uint64_t m = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1ull);
+					m &= lo >= 8 ? 0ull : ~((1ull << (8 * lo)) - 1ull);
+					dd.x &= (uint32_t) m;
+					dd.y &= (uint32_t) (m >> 32);
+				};
+				mask8(da, i0);
+				mask8(db, i0 + 8);
+			}
+			expand8s(da, v);
+			expand8s(db, v + 4);
+		} else {
+			auto lowat = [&](uint32_t l) -> uint32_t { return (l >= L0 && l < L1) ? (uint32_t) (int32_t) (int8_t) src[l - L0] : 0u; };
+			gather8(lowat, R.pos, R.val, R.zd0, i0, Ia, Ib, Ea, ecnt, v);
+			gather8(lowat, R.pos, R.val, R.zd0, i0 + 8, Ia, Ib, Ea, ecnt, v + 4);
+		}
+		const uint32_t ta = lane_prefix8(v) & 0xFFFFu;
+		const uint32_t tb = lane_prefix8(v + 4) & 0xFFFFu;
+		const uint32_t tot = (ta + tb) & 0xFFFFu;
+		const uint32_t inc = wave_incl_scan_dpp(tot);
+		const uint32_t ba = (base + inc - tot) & 0xFFFFu, bb = (ba + ta) & 0xFFFFu;
+		const uint32_t ba2 = ba | (ba << 16), bb2 = bb | (bb << 16);
+#pragma unroll
+		for (int h = 0; h < 4; h++) {
+			v[h] = pk_add16(v[h], ba2);
+			v[4 + h] = pk_add16(v[4 + h], bb2);
+		}
+		if (shift) { // ex_zd.c:396 do_rev_qts_inplace
+#pragma unroll
+			for (int h = 0; h < 8; h++)
+				v[h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, v[h]) << qq);
+		}
+#pragma unroll
+		for (int hh = 0; hh < 2; hh++) {
+			const uint32_t ia = i0 + 8 * hh;
+			if (!ragged || (ia >= Ia && ia + 8 <= Ib)) {
+				const uint4 vv = make_uint4(v[4 * hh], v[4 * hh + 1], v[4 * hh + 2], v[4 * hh + 3]);
+				__builtin_memcpy(R.out + ia, &vv, 16);
+			} else {
+#pragma unroll
+				for (uint32_t h = 0; h < 8; h++)
+					if (ia + h >= Ia && ia + h < Ib)
+						R.out[ia + h] = (int16_t) (v[4 * hh + (h >> 1)] >> (16 * (h & 1)));
+			}
+		}
+		base += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+	}
+}
+
 // one-byte values out of their deltas, four at a time (trans.c:74 zig-zag of a byte)
 __device__ __forceinline__ uint32_t zz_bytes(uint32_t d)
 {
@@ -940,10 +1024,10 @@ __device__ __forceinline__ uint32_t zz_bytes(uint32_t d)
 constexpr int WGE = EMIT_WG; // eight waves, each on its own, share the tables
 constexpr uint32_t EMIT_UC = 16; // units of work a workgroup takes from the global counter at a time
 
-struct EmitStg { // the waves' staging buffers; emit_samples reads up to 8 bytes in front of / 12 behind a buffer's content
+struct EmitStg { // the waves' staging buffers; emit_samples16 reads up to 16 bytes in front of / 20 behind a buffer's content
 	uint8_t pre[16];
 	uint8_t s[WGE / 64][EMIT_STG];
-	uint8_t post[16];
+	uint8_t post[32];
 };
 
 template <int RU>
@@ -1068,7 +1152,7 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 			wave_lds_sync();
 			if (fused) {
 				if (quota)
-					emit_samples<false>(stg, R, emit_plan(R, (uint32_t) obase, quota, B0, lane, key), lane);
+					emit_samples16(stg, R, emit_plan(R, (uint32_t) obase, quota, B0, lane, key), lane);
 			} else {
 				// the one-byte stream, for k_low_decode_chunked: 16-byte stores
 				for (uint32_t o = lane * 16; o < quota; o += 64 * 16) {
