@@ -955,12 +955,11 @@ __device__ __forceinline__ void emit_samples16(const uint8_t *src, const EmitRea
 			const uint32_t d0 = s32[j], d1 = s32[j + 1], d2 = s32[j + 2], d3 = s32[j + 3], d4 = s32[j + 4];
 			uint2 da = make_uint2(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh));
 			uint2 db = make_uint2(__builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh));
-			if (ragged) {
+			if (g < Ia) { // the first round: what lies in front of the wave's first sample does not count
+				// (behind its last sample nothing needs a mask: those deltas only reach samples that are not stored)
 				auto mask8 = [&](uint2 &dd, uint32_t ia) {
 					const uint32_t lo = Ia > ia ? (Ia - ia < 8 ? Ia - ia : 8u) : 0u;
-					const uint32_t hi = Ib > ia ? (Ib - ia < 8 ? Ib - ia : 8u) : 0u;
-					uint64_t m = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1ull);
-					m &= lo >= 8 ? 0ull : ~((1ull << (8 * lo)) - 1ull);
+					const uint64_t m = lo >= 8 ? 0ull : ~((1ull << (8 * lo)) - 1ull);
 					dd.x &= (uint32_t) m;
 					dd.y &= (uint32_t) (m >> 32);
 				};
@@ -996,7 +995,7 @@ __device__ __forceinline__ void emit_samples16(const uint8_t *src, const EmitRea
 			if (!ragged || (ia >= Ia && ia + 8 <= Ib)) {
 				const uint4 vv = make_uint4(v[4 * hh], v[4 * hh + 1], v[4 * hh + 2], v[4 * hh + 3]);
 				__builtin_memcpy(R.out + ia, &vv, 16);
-			} else {
+			} else if (ia < Ib && ia + 8 > Ia) { // (the one group that straddles the wave's first or last sample)
 #pragma unroll
 				for (uint32_t h = 0; h < 8; h++)
 					if (ia + h >= Ia && ia + h < Ib)
