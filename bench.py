@@ -340,18 +340,9 @@ def libzstd_frames(torch, press, b, steps, nreads=1024):
     import ctypes
     import struct
 
-    z = None
-    for name in ("/opt/conda/lib/libzstd.so.1", "libzstd.so.1", "libzstd.so"):
-        try:
-            z = ctypes.CDLL(name)
-            break
-        except OSError:
-            continue
+    z = press.open_libzstd()  # (the copy already in the process first: two versions side by side abort)
     if z is None:
         return None
-    z.ZSTD_compress.restype = ctypes.c_size_t
-    z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-    z.ZSTD_isError.argtypes = [ctypes.c_size_t]
     k = min(nreads, b.R)
     n = b.n[:k]
     d_off, d_n = b.d_off[:k].contiguous(), b.d_n[:k].contiguous()

@@ -65,10 +65,15 @@ struct Inflaters {
 			z_compress2 = (decltype(z_compress2)) dlsym(hz, "compress2");
 			z_bound = (decltype(z_bound)) dlsym(hz, "compressBound");
 		}
-		for (const char *n : { "libzstd.so.1", "libzstd.so", "/opt/conda/lib/libzstd.so.1" }) {
-			if ((hs = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
-				break;
+		// (what the process already holds first: two copies of libzstd in one process free each other's memory)
+		if (!(hs = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) {
+			for (const char *n : { "libzstd.so.1", "libzstd.so" }) {
+				if ((hs = dlopen(n, RTLD_NOW | RTLD_LOCAL)))
+					break;
+			}
 		}
+		if (!hs)
+			hs = dlopen("/opt/conda/lib/libzstd.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
 		if (hs) {
 			zs_decompress = (decltype(zs_decompress)) dlsym(hs, "ZSTD_decompress");
 			zs_content_size = (decltype(zs_content_size)) dlsym(hs, "ZSTD_getFrameContentSize");

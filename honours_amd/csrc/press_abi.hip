@@ -145,9 +145,19 @@ bool zstd_open()
 	if (zstd_fn.tried)
 		return zstd_fn.compress != nullptr;
 	zstd_fn.tried = true;
-	const char *names[] = { "/opt/conda/lib/libzstd.so.1", "libzstd.so.1", "libzstd.so", nullptr };
-	for (int i = 0; names[i]; i++) {
-		void *h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+	// Bind to the libzstd the process already holds, if any: a SECOND copy of the library (another version opened by
+	// absolute path) resolves its internal calls through the first one's symbols when that one is in the global
+	// scope, and frees what the other allocated - glibc aborts with "free(): invalid pointer" / "munmap_chunk()"
+	// (round 2: rocprofv3's tool library links the system's 1.4.8, this opened conda's 1.4.9; RTLD_LOCAL does not
+	// prevent it).  So: what is loaded, then the soname, and an absolute path only last and bound to itself.
+	struct { const char *name; int flags; } names[] = {
+		{ "libzstd.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD },
+		{ "libzstd.so.1", RTLD_NOW | RTLD_LOCAL },
+		{ "libzstd.so", RTLD_NOW | RTLD_LOCAL },
+		{ "/opt/conda/lib/libzstd.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND },
+		{ nullptr, 0 } };
+	for (int i = 0; names[i].name; i++) {
+		void *h = dlopen(names[i].name, names[i].flags);
 		if (!h)
 			continue;
 		zstd_fn.compress = (decltype(zstd_fn.compress)) dlsym(h, "ZSTD_compress");

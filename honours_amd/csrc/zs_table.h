@@ -1051,6 +1051,11 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, 
 				return W_BAD;
 			if (!seqs && dst + R > cap)
 				return W_BAD;
+			// a block with sequences delivers at least its literals, so the literals of all such blocks fit in
+			// `cap` bytes of a valid frame: checked BEFORE the pieces are queued (the literals space is a slot of
+			// `cap` bytes and the copy / fill / Huffman kernels carry out whatever was queued)
+			if (seqs && lit_pos + R > cap)
+				return W_BAD;
 			// literals: straight into the content when no sequences follow, else into the frame's
 			// literals space (lit = true) from which the sequences copy them
 			uint64_t src = at + lh;
@@ -1185,6 +1190,8 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, 
 				if (out + tail > cap)
 					return W_BAD;
 				sink.seq_end((uint32_t) tail);
+				if (out + tail - dst > 131072) // Block_Maximum_Size also bounds what a block delivers (RFC 8878 3.1.1.2)
+					return W_BAD;
 				produced = (uint32_t) (out + tail - dst);
 				lit_pos += R;
 			}

@@ -130,6 +130,28 @@ def load_library(path=LIB_PATH):
     return _lib
 
 
+def open_libzstd():
+    """ctypes handle to a libzstd for tests and bench.py (never the product path), or None.  The copy the process
+    already holds comes first: a second copy of another version frees the first one's allocations and glibc aborts
+    ("free(): invalid pointer" - round 2's rocprofv3 run); an absolute path only last, bound
+    to itself (RTLD_DEEPBIND)."""
+    import os
+    tries = [("libzstd.so.1", os.RTLD_NOW | os.RTLD_NOLOAD), ("libzstd.so.1", os.RTLD_NOW), ("libzstd.so", os.RTLD_NOW),
+             ("/opt/conda/lib/libzstd.so.1", os.RTLD_NOW | os.RTLD_DEEPBIND)]
+    for name, mode in tries:
+        try:
+            z = ctypes.CDLL(name, mode=mode)
+        except OSError:
+            continue
+        z.ZSTD_decompress.restype = ctypes.c_size_t
+        z.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+        z.ZSTD_compress.restype = ctypes.c_size_t
+        z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        z.ZSTD_isError.argtypes = [ctypes.c_size_t]
+        return z
+    return None
+
+
 def last_error():
     return load_library().press_hip_last_error().decode()
 

@@ -219,15 +219,18 @@ struct HostSink {
 	void sync() const {}
 	void fetch(uint8_t *dst, const uint8_t *src, uint32_t n) { memcpy(dst, src, n); }
 	// blocks with sequences: their literals go to a buffer of their own, the sequences copy from it
-	std::vector<uint8_t> lits;
+	// (exactly `cap` bytes on the heap, like the device's literals slot: ASan sees a piece that runs past it)
+	uint8_t *lits = nullptr;
+	uint64_t cap = 0;
 	uint64_t blk_lit = 0, blk_out = 0;
-	uint8_t *where(uint64_t dst, uint32_t n, bool lit)
+	~HostSink() { free(lits); }
+	uint8_t *where(uint64_t dst, uint32_t, bool lit)
 	{
 		if (!lit)
 			return out + dst;
-		if (lits.size() < dst + n + 1)
-			lits.resize(dst + n + 1);
-		return lits.data() + dst;
+		if (!lits)
+			lits = (uint8_t *) malloc(cap ? cap : 1);
+		return lits + dst;
 	}
 	void copy(uint64_t src, uint64_t dst, uint32_t n, bool lit) { memcpy(where(dst, n, lit), f + src, n); }
 	void fill(uint64_t src, uint64_t dst, uint32_t n, bool lit) { memset(where(dst, n, lit), f[src], n); }
@@ -240,7 +243,7 @@ struct HostSink {
 	}
 	void seq(uint32_t, uint32_t ll, uint32_t ml, uint32_t off)
 	{
-		memcpy(out + blk_out, lits.data() + blk_lit, ll);
+		memcpy(out + blk_out, lits + blk_lit, ll);
 		blk_lit += ll;
 		blk_out += ll;
 		for (uint32_t i = 0; i < ml; i++, blk_out++) // (byte by byte: a match may overlap itself)
@@ -248,7 +251,7 @@ struct HostSink {
 	}
 	void seq_end(uint32_t tail)
 	{
-		memcpy(out + blk_out, lits.data() + blk_lit, tail);
+		memcpy(out + blk_out, lits + blk_lit, tail);
 		blk_out += tail;
 	}
 	int64_t tree(const uint8_t *w, uint32_t t)
@@ -286,6 +289,7 @@ int64_t zsm_decode(const uint8_t *frame, uint64_t len, uint8_t *out, uint64_t ca
 	s.f = frame;
 	s.out = out;
 	s.tl = 0;
+	s.cap = cap;
 	zs::ReadWork k;
 	return zs::walk_frame(frame, len, cap, s, k);
 }

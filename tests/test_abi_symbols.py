@@ -92,3 +92,32 @@ def test_scratch_registry_without_gpu():
     if not torch.cuda.is_available():
         assert nbytes.value == 0
     lib.press_hip_shutdown()  # harmless without a context
+
+
+def test_one_libzstd_per_process():
+    """round 2's abort under rocprofv3 ("munmap_chunk(): invalid pointer"): the profiler's tool library had the
+    system's libzstd in the global scope and the library / bench.py opened another version by absolute path - the
+    second copy's internal calls bound to the first and freed its memory.  With a libzstd preloaded the way the
+    profiler does it, both openers must bind to THAT copy and compress without aborting."""
+    import glob
+    import subprocess
+    import sys
+
+    sys_z = [p for p in glob.glob("/usr/lib/x86_64-linux-gnu/libzstd.so.1") + glob.glob("/lib/x86_64-linux-gnu/libzstd.so.1")]
+    if not sys_z:
+        pytest.skip("no system libzstd to preload")
+    code = (
+        "import ctypes, numpy as np\n"
+        "from honours_amd import press\n"
+        "z = press.open_libzstd()\n"
+        "src = np.tile(np.arange(50, dtype=np.uint8), 4000); dst = np.zeros(src.size + 1024, dtype=np.uint8)\n"
+        "c = z.ZSTD_compress(dst.ctypes.data, dst.size, src.ctypes.data, src.size, 1)\n"
+        "assert not z.ZSTD_isError(c) and 0 < c < src.size\n"
+        "lib = press.load_library()\n"
+        "assert press.bound('zstd_svb_zd', 100000) > 100000\n"   # the library's own dlopen (zstd_open)
+        "c = z.ZSTD_compress(dst.ctypes.data, dst.size, src.ctypes.data, src.size, 1)\n"
+        "assert not z.ZSTD_isError(c)\n"
+        "print('ok')\n")
+    env = dict(os.environ, LD_PRELOAD=sys_z[0], PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "ok" in p.stdout, (p.returncode, p.stderr[-500:])

@@ -26,18 +26,11 @@ MODEL_SO = os.path.join(ROOT, "oracle", "libzsframe_model.so")
 
 
 def _zstd():
-    for name in ("/opt/conda/lib/libzstd.so.1", "libzstd.so.1", "libzstd.so"):
-        try:
-            z = ctypes.CDLL(name)
-        except OSError:
-            continue
-        z.ZSTD_decompress.restype = ctypes.c_size_t
-        z.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
-        z.ZSTD_compress.restype = ctypes.c_size_t
-        z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-        z.ZSTD_isError.argtypes = [ctypes.c_size_t]
-        return z
-    pytest.skip("no libzstd")
+    from honours_amd import press
+    z = press.open_libzstd()
+    if z is None:
+        pytest.skip("no libzstd")
+    return z
 
 
 def zstd_decode(z, frame, cap):
@@ -445,3 +438,92 @@ def test_device_reader_on_many_damaged_frames():
             assert b is None, "frame %d: the host reader refuses it, the device does not" % k
             refused += 1
     assert refused > 50
+
+
+FORGED_LITERALS = bytes([0x28, 0xB5, 0x2F, 0xFD, 0x20, 24, 0x4D, 0x00, 0x00,   # frame header, one last compressed block of 9 bytes
+                         0x0D, 0x00, 0x20, 0xAA,                                # literals: RLE, R = 131072
+                         0x01, 0x00, 0x01, 0x00, 0x80])                         # one sequence, predefined tables
+
+
+def test_model_refuses_forged_literals():
+    """a block with sequences whose literals do not fit the room is refused before anything is queued"""
+    m = ctypes.CDLL(MODEL_SO)
+    m.zsm_decode.restype = ctypes.c_int64
+    m.zsm_decode.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    a = np.frombuffer(FORGED_LITERALS, dtype=np.uint8).copy()
+    out = np.zeros(64, dtype=np.uint8)
+    assert m.zsm_decode(a.ctypes.data, a.size, out.ctypes.data, 27) == -1
+    assert not out.any()
+
+
+@gpu
+def test_device_refuses_forged_literals():
+    """a ~18-byte frame whose RLE literals claim 131072 bytes, in the batch's LAST and shortest read
+    (its literals slot is the end of the scratch arena): refused, the neighbours decode, the library reports no fault"""
+    from honours_amd import press
+    rng = np.random.default_rng(5)
+    reads = [rng.integers(300, 700, int(n)).astype(np.int16) for n in (40000, 9000, 10)]
+    good = press.press_batch_host("zstd_svb_zd", reads)
+    for at in (2, 1, 0):
+        bad = list(good)
+        bad[at] = FORGED_LITERALS
+        back = press.depress_batch_host("zstd_svb_zd", bad, [len(s) for s in reads])
+        for k in range(3):
+            if k == at:
+                assert back[k] is None
+            else:
+                assert back[k] is not None and np.array_equal(back[k], reads[k]), (at, k)
+    # and the undamaged batch still decodes afterwards
+    back = press.depress_batch_host("zstd_svb_zd", good, [len(s) for s in reads])
+    assert all(np.array_equal(b, s) for b, s in zip(back, reads))
+    assert press.load_library().press_hip_synchronize() == 0
+
+
+@gpu
+def test_device_reader_on_damaged_libzstd_frames():
+    """bit-flipped / truncated frames of ZSTD_compress at levels 1, 3 and 9 (sequences, repeated tables): what the
+    host build of the reader refuses the device refuses, what it decodes the device decodes to the same samples or
+    refuses later (the svb layer); undamaged neighbours are intact"""
+    from honours_amd import press
+    z = _zstd()
+    oracle = _libs.oracle()
+    m = ctypes.CDLL(MODEL_SO)
+    m.zsm_decode.restype = ctypes.c_int64
+    m.zsm_decode.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    rng = np.random.default_rng(78)
+    # reads with repeats, so that libzstd finds matches
+    base = []
+    for n in (3000, 20000, 70000):
+        s = rng.integers(300, 700, int(n)).astype(np.int16)
+        s[n // 2:n // 2 + n // 4] = s[:n // 4]
+        base.append(s)
+    reads, frames, verdict = [], [], []
+    for level in (1, 3, 9):
+        good = _libzstd_frames(z, oracle, base, level)
+        for k in range(60):
+            j = k % 3
+            f = bytearray(good[j])
+            kind = k % 5
+            if kind == 0:
+                f = f[:int(rng.integers(0, len(f)))]
+            elif kind != 4:
+                for _ in range(int(rng.integers(1, 4))):
+                    at = int(rng.integers(0, min(len(f), 64))) if rng.integers(0, 3) == 0 else int(rng.integers(0, len(f)))
+                    f[at] ^= 1 << int(rng.integers(0, 8))
+            f = bytes(f) if len(f) else b"\0"
+            a = np.frombuffer(f, dtype=np.uint8).copy()
+            cap = 4 + (len(base[j]) + 3) // 4 + 2 * len(base[j])
+            out = np.zeros(cap + 64, dtype=np.uint8)
+            verdict.append(int(m.zsm_decode(a.ctypes.data, len(f), out.ctypes.data, cap)))
+            reads.append(base[j])
+            frames.append(f)
+    back = press.depress_batch_host("zstd_svb_zd", frames, [len(s) for s in reads])
+    refused = 0
+    for k, (s, b, v) in enumerate(zip(reads, back, verdict)):
+        if k % 5 == 4:
+            assert b is not None and np.array_equal(b, s), k
+        if v == -1:
+            assert b is None, "frame %d: the host reader refuses it, the device does not" % k
+            refused += 1
+    assert refused > 20
+    assert press.load_library().press_hip_synchronize() == 0

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 name=$1; ctrs=$2; shift 3
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/pmc_$name -- "$@" > gpurun_out/pmc_$name.out 2> gpurun_out/pmc_$name.err
+timeout -k 10 ${PROF_TIMEOUT:-600} rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/pmc_$name -- "$@" > gpurun_out/pmc_$name.out 2> gpurun_out/pmc_$name.err
 python3 - "$name" <<'PY'
 import csv,glob,collections,sys
 f=glob.glob("gpurun_out/pmc_%s/*/*counter_collection.csv"%sys.argv[1])[0]

@@ -34,7 +34,7 @@ def run_pass(method, counter, tag):
     subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
                     "python3", os.path.join(ROOT, "bench.py"), "--method", method, "--steps", "2", "--warmup", "1",
                     "--no-cpu", "--no-sub"], check=True, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                   cwd=ROOT)
+                   cwd=ROOT, timeout=600)  # (an abort under the profiler must end the call, not hang the box)
     f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
     agg, disp = collections.defaultdict(float), collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
