@@ -38,6 +38,9 @@ sys.path.insert(0, ROOT)
 
 VBZ_RATIO = 2.928430  # data/reads.blow5.test:11 (zstd-svb-zd on NA12878)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+# wave64 VALU issue peak: an integer VALU instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU =
+# 4 x SQ_INSTS_VALU in profiles/*pmc*.txt): 256 CUs x 4 SIMDs x 2.4 GHz / 4
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4
 HEADLINE = "shuffman_vbe21_zd"
 CONFIG5_LEN = 200000
 CONFIG5_READS = 4096
@@ -108,6 +111,22 @@ def measured_traffic(m, reads, seed, fixed_len):
         w = t.get("workload", {})
         if (w.get("method"), w.get("reads_per_gpu"), w.get("seed"), w.get("fixed_len")) == (m, reads, seed, fixed_len):
             return t.get("traffic_bytes_per_launch"), os.path.relpath(f, ROOT)
+    return None, None
+
+
+def measured_valu(m, reads, seed, fixed_len):
+    """Wave-level VALU instructions per launch of the method's kernels from the committed counter pass
+    (profiles/*valu*.json: rocprofv3 --pmc SQ_INSTS_VALU ..., tools/valu.py) for this exact workload, or None."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*valu*.json")), reverse=True):
+        try:
+            t = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        w = t.get("workload", {})
+        if (w.get("method"), w.get("reads_per_gpu"), w.get("seed"), w.get("fixed_len")) == (m, reads, seed, fixed_len):
+            return t.get("valu_insts_per_call"), os.path.relpath(f, ROOT)
     return None, None
 
 
@@ -191,7 +210,7 @@ def run_method(torch, press, shard, b, m, steps, warmup, world, dist, seed, chec
     kpress_ms = float(np.mean(kpress)) if kpress else press_ms
     kdepress_ms = float(np.mean(kdepress)) if kdepress else depress_ms
     # the only collective: 24 bytes of totals (+ the slowest rank's time) over RCCL
-    raw_all, comp_all, reads_all, elapsed = shard.reduce_totals(b.raw_bytes, comp_bytes, b.R, elapsed, b.dev)
+    raw_all, comp_all, reads_all, elapsed, per_rank = shard.gather_totals(b.raw_bytes, comp_bytes, b.R, elapsed, b.dev)
 
     # Roofline.  Algorithmic bytes of a call = sum over the batch of 2n (int16
     # samples) + c (compressed stream), each crossing HBM once.
@@ -201,18 +220,32 @@ def run_method(torch, press, shard, b, m, steps, warmup, world, dist, seed, chec
     alg = b.raw_bytes + comp_bytes
     kern = KERNELS.get(m, ("k_low_encode_chunked", "k_low_decode_chunked<false>"))
     traffic, tsrc = measured_traffic(m, b.R, seed, b.fixed_len)
+    valu, vsrc = measured_valu(m, b.R, seed, b.fixed_len)
 
     def roof(which, name, ms, call_ms, key):
         own = kernel_own_bytes(m, which, b.raw_bytes, comp_bytes, b.total_samples)
         gbps = own / (ms * 1e-3) / 1e9
         call_gbps = alg / (call_ms * 1e-3) / 1e9
-        return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
-                "traffic": traffic.get(key) if traffic else None, "traffic_source": tsrc,
-                "kernel_bytes_per_launch": own, "avg_launch_ms": round(ms, 4),
-                "algorithmic_bytes_per_call": alg, "whole_call_ms": round(call_ms, 4),
-                "call_achieved": round(call_gbps, 1), "call_frac": round(call_gbps / HBM_PEAK_GBPS, 4),
-                "limiter": LIMITER.get(m, "hbm")}
+        lim = LIMITER.get(m, "hbm")
+        # achieved / peak / frac: always the HBM roofline of the timed kernel (the contract's figure); `bound`
+        # names what the counter passes say limits it, and for VALU-bound kernels `valu` is that roofline:
+        # wave instructions per launch (counter pass in profiles/) / live kernel time against the issue peak
+        r = {"kernel": name, "bound": "valu" if lim.startswith("valu") else "hbm", "achieved": round(gbps, 1),
+             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBPS, 4),
+             "traffic": traffic.get(key) if traffic else None,
+             "traffic_source": ("from profile %s (counter pass of the same workload, not measured in this run)" % tsrc)
+             if tsrc else None,
+             "kernel_bytes_per_launch": own, "avg_launch_ms": round(ms, 4),
+             "algorithmic_bytes_per_call": alg, "whole_call_ms": round(call_ms, 4),
+             "call_achieved": round(call_gbps, 1), "call_frac": round(call_gbps / HBM_PEAK_GBPS, 4),
+             "limiter": lim}
+        if valu and valu.get(key + "_timed"):
+            gi = valu[key + "_timed"] / (ms * 1e-3) / 1e9
+            r["valu"] = {"wave_insts_per_launch": valu[key + "_timed"], "achieved": round(gi, 1),
+                         "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-inst/s",
+                         "frac": round(gi / VALU_PEAK_GINST, 4),
+                         "source": "from profile %s (SQ_INSTS_VALU of the timed kernels) / this run's kernel time" % vsrc}
+        return r
 
     r_press = roof(0, kern[0], kpress_ms, press_ms, "press")
     r_depress = roof(1, kern[1], kdepress_ms, depress_ms, "depress")
@@ -237,6 +270,11 @@ def run_method(torch, press, shard, b, m, steps, warmup, world, dist, seed, chec
         "depress_MBps": round(b.raw_bytes / (depress_ms * 1e-3) / 1e6, 1),
         "roofline": dominant,
         "roofline_other": other,
+        # what the one collective brought back: the world RCCL saw and the spread of the ranks' step times
+        "ranks": {"world_size": len(per_rank), "backend": "nccl (RCCL)" if world > 1 else "none (one process)",
+                  "ms_per_step_min": round(min(r[3] for r in per_rank) / steps * 1e3, 4),
+                  "ms_per_step_max": round(max(r[3] for r in per_rank) / steps * 1e3, 4),
+                  "reads": reads_all},
     }
 
 
@@ -254,6 +292,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-sub", action="store_true", help="headline only: no sub-records, no e2e leg")
     ap.add_argument("--no-check", action="store_true", help=argparse.SUPPRESS)  # diagnostic kernel builds only
+    ap.add_argument("--full-batches", type=int, default=61,
+                    help="config4_500k_equiv: distinct 8192-read batches (61 = 499 712 reads; 0 = skip)")
+    ap.add_argument("--full-reps", type=int, default=6, help="config4_500k_equiv: timed steps per batch")
     args = ap.parse_args()
 
     import torch
@@ -263,8 +304,8 @@ def main():
 
     rank, world, local_rank = shard.world_info()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit("bench.py --gpus %d under a world of %d ranks: launch N>1 with python -m "
+                         "torch.distributed.run --nproc-per-node N bench.py --gpus N" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -320,16 +361,134 @@ def main():
                     rec["libzstd_frames"] = libzstd_frames(torch, press, b, args.steps)
                 line["configs"][key] = rec
             line["e2e_host"] = e2e_host(torch, press, b, m)
+            line["per_read_api"] = per_read_api(press, b, m)
             del b
             torch.cuda.empty_cache()
             b5 = Batch(torch, press, synth, args.seed, 0, CONFIG5_READS, dev, CONFIG5_LEN)
             rec = run_method(torch, press, shard, b5, m, args.steps, args.warmup, 1, dist, args.seed)
             rec["steps"], rec["warmup"] = args.steps, args.warmup
             line["configs"]["config5_shape_1gpu"] = rec
+            del b5
+            torch.cuda.empty_cache()
+            if args.full_batches > 0:
+                line["configs"]["config4_500k_equiv"] = full_scale(torch, press, synth, dev, m, args.seed, reads,
+                                                                   args.full_batches, args.full_reps)
         print(json.dumps(line), flush=True)
 
     if world > 1:
         dist.destroy_process_group()
+
+
+def full_scale(torch, press, synth, dev, m, seed, reads, nbatches, reps):
+    """The metric's own scale (BASELINE: NA12878, 500 000 reads): `nbatches` DISTINCT batches of `reads`
+    NA12878-like reads - batch k holds reads [k * reads, (k + 1) * reads) of the same generator, made on the
+    device, untimed - each through press_batch + depress_batch `reps` times behind one warm-up step, timed with
+    events on the launch stream; every batch checked lossless.  Aggregate ratio and MB/s over all of them, and the
+    spread over the batches (the longest reads, 5.7 M samples, sit in the same launch as 2 k ones)."""
+    if m.startswith("shuffman"):
+        press.load_table()
+    tot_raw = tot_comp = tot_reads = 0
+    tot_press = tot_depress = 0.0
+    per = []
+    longest = 0
+    t_wall = time.perf_counter()
+    for k in range(nbatches):
+        b = Batch(torch, press, synth, seed, k * reads, reads, dev, None)
+        caps, d_out, d_out_off, d_in_off = b.arena(torch, press, m)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps + 1)]
+        for it in range(reps + 1):  # the first pass warms up (and sizes the scratch for this batch)
+            if it >= 1:
+                ev[2 * (it - 1)].record()
+            press.press_batch(m, b.sig, b.d_off, b.d_n, d_out, d_out_off, b.d_len)
+            if it >= 1:
+                ev[2 * (it - 1) + 1].record()
+            press.depress_batch(m, d_out, d_in_off, b.d_len, b.d_back, b.d_off, b.d_n, b.d_outn)
+        ev[2 * reps].record()
+        torch.cuda.synchronize()
+        lens = b.d_len.cpu().numpy()
+        assert (lens > 0).all() and (lens < caps).all(), "batch %d: a read failed to compress" % k
+        assert torch.equal(b.d_back, b.sig), "batch %d: round trip is not lossless" % k
+        p_ms = sum(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(reps)) / reps
+        d_ms = sum(ev[2 * i + 1].elapsed_time(ev[2 * i + 2]) for i in range(reps)) / reps
+        comp = int(lens.sum())
+        tot_raw += b.raw_bytes
+        tot_comp += comp
+        tot_reads += b.R
+        tot_press += p_ms
+        tot_depress += d_ms
+        longest = max(longest, int(b.n.max()))
+        per.append((b.raw_bytes / ((p_ms + d_ms) * 1e-3) / 1e6, b.raw_bytes / comp, p_ms, d_ms))
+        del b, d_out, d_out_off, d_in_off
+    v = [x[0] for x in per]
+    return {
+        "what": "%d distinct batches x %d NA12878-like reads (reads 0 .. %d of the generator), press_batch + "
+                "depress_batch, device resident, every batch checked lossless; %d timed steps per batch behind "
+                "one warm-up" % (nbatches, reads, nbatches * reads - 1, reps),
+        "method": m, "reads": tot_reads, "samples": tot_raw // 2, "raw_bytes": tot_raw, "compressed_bytes": tot_comp,
+        "longest_read": longest,
+        "ratio": round(tot_raw / tot_comp, 6), "ratio_vs_vbz": round(tot_raw / tot_comp / VBZ_RATIO, 6),
+        "value": round(tot_raw / ((tot_press + tot_depress) * 1e-3) / 1e6, 1), "unit": "MB/s",
+        "press_MBps": round(tot_raw / (tot_press * 1e-3) / 1e6, 1),
+        "depress_MBps": round(tot_raw / (tot_depress * 1e-3) / 1e6, 1),
+        "gpu_ms_timed": round((tot_press + tot_depress) * reps, 1),
+        "per_batch": {"value_min": round(min(v), 1), "value_max": round(max(v), 1),
+                      "ratio_min": round(min(x[1] for x in per), 6), "ratio_max": round(max(x[1] for x in per), 6),
+                      "press_ms_min": round(min(x[2] for x in per), 4), "press_ms_max": round(max(x[2] for x in per), 4),
+                      "depress_ms_min": round(min(x[3] for x in per), 4),
+                      "depress_ms_max": round(max(x[3] for x in per), 4)},
+        "wall_s_incl_generation": round(time.perf_counter() - t_wall, 1),
+    }
+
+
+def per_read_api(press, b, m, nreads=256):
+    """the per-read drop-in symbols as press/test.c:1783-1810 calls them - X_press / X_depress of
+    ONE read per call, host pointers in and out, the clock around the call alone (buffers allocated outside, as
+    the harness does) - on the first `nreads` reads of the batch.  Launch- and PCIe-latency bound by
+    construction: the batch API is the throughput path."""
+    import ctypes
+
+    lib = press.load_library()
+    k = min(nreads, b.R)
+    host = b.sig[: int(b.starts[k])].cpu().numpy()
+    reads = [np.ascontiguousarray(host[int(b.starts[r]): int(b.starts[r]) + int(b.n[r])]) for r in range(k)]
+    _, pname, dname, kind = press._SYMS[m]
+    if kind != "shuff":
+        return None
+    tab = press.default_table()
+    fp, fd = getattr(lib, pname), getattr(lib, dname)
+    fp.restype = ctypes.c_int
+    fp.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+    fd.restype = ctypes.c_int
+    fd.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+    outs, backs, lens = [], [], []
+    for s in reads:
+        outs.append(np.zeros(press.bound(m, s.size) + 1024, dtype=np.uint8))
+        backs.append(np.zeros(s.size + 64, dtype=np.int16))
+    tp = td = 0.0
+    for it in range(2):  # the first pass warms up
+        tp = td = 0.0
+        lens = []
+        for s, o in zip(reads, outs):
+            nout = ctypes.c_uint64(o.size)
+            t0 = time.perf_counter()
+            ret = fp(tab.se, s.ctypes.data, s.size, o.ctypes.data, ctypes.byref(nout))
+            tp += time.perf_counter() - t0
+            assert ret == 0
+            lens.append(int(nout.value))
+        for s, o, c, bk in zip(reads, outs, lens, backs):
+            nn = ctypes.c_uint32(s.size)
+            t0 = time.perf_counter()
+            ret = fd(tab.root, o.ctypes.data, c, bk.ctypes.data, ctypes.byref(nn))
+            td += time.perf_counter() - t0
+            assert ret == 0 and nn.value == s.size
+    assert all(np.array_equal(bk[: s.size], s) for s, bk in zip(reads, backs)), "per-read round trip"
+    raw = 2 * sum(s.size for s in reads)
+    return {"what": "%s_press_16 / _depress_16, one read per call with host pointers (press/test.c:1783-1810), "
+                    "the clock around each call" % m,
+            "symbols": [pname, dname], "reads": k, "raw_bytes": raw, "unit": "MB/s",
+            "press_MBps": round(raw / tp / 1e6, 1), "depress_MBps": round(raw / td / 1e6, 1),
+            "value": round(raw / (tp + td) / 1e6, 1),
+            "press_us_per_call": round(tp / k * 1e6, 1), "depress_us_per_call": round(td / k * 1e6, 1)}
 
 
 def libzstd_frames(torch, press, b, steps, nreads=1024):

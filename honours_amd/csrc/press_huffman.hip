@@ -267,6 +267,11 @@ __device__ __forceinline__ void wave_lds_sync()
 #ifndef HUF_SYNC_PER_CU
 #define HUF_SYNC_PER_CU 2
 #endif
+// the run-up in eighths of a subsequence (4: the half in front - 128 bits of NA12878's 256).  k_huf_sync's cost goes
+// with run-up + subsequence; a shorter run-up leaves more wrong guesses to k_huf_fix's dense rounds.
+#ifndef HUF_RUNUP_EIGHTHS
+#define HUF_RUNUP_EIGHTHS 4
+#endif
 constexpr int WGS = 1024;
 constexpr int SYNC_S = 65; // dwords per row of a wave's image: 64 lanes and, in front, the subsequence before the first
 
@@ -320,6 +325,7 @@ template <int RU>
 __global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(DecodeArgs a)
 {
 	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW;
+	constexpr int RUNUP = OWN * HUF_RUNUP_EIGHTHS / 8; // bits of the run-up (the last RUNUP bits of the subsequence in front)
 	constexpr int S = SYNC_S;
 	__shared__ __attribute__((aligned(16))) uint32_t lut[1 << HUF_LUT_BITS];
 	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(Decod
 		const bool first_known = lane == 0 && exact;
 		uint32_t f, c0, c, dz, dv;
 		{
-			const uint32_t g = len_scan<S>(rcol, lut, lut2, a.huff, first_known ? HEND : (uint32_t) RU, OWN, nbr, c0, dz);
+			const uint32_t g = len_scan<S>(rcol, lut, lut2, a.huff, first_known ? HEND : (uint32_t) (OWN - RUNUP), OWN, nbr, c0, dz);
 			f = g == HEND ? HEND : g - OWN;
 			if (g == HEND && nb > 0)
 				f = 0; // the guess ran into a bit pattern that is no code: any guess will do
@@ -1262,7 +1268,10 @@ __global__ __launch_bounds__(64) void k_huff_tiles(DecodeArgs a)
 	}
 }
 
-constexpr int HUF_FIX_LAUNCHES = 4; // rounds of k_huf_fix (an ordinary table is through after two)
+#ifndef HUF_FIX_ROUNDS
+#define HUF_FIX_ROUNDS 4
+#endif
+constexpr int HUF_FIX_LAUNCHES = HUF_FIX_ROUNDS; // rounds of k_huf_fix (an ordinary table is through after two)
 
 template <int RU>
 static void run_huff_decode(const DecodeArgs &a, hipStream_t s)

@@ -2,9 +2,10 @@
 
 Reads are independent (thesis/probspace/focus.tex:177-183), so the path shards with no
 data exchange: rank k of W owns a contiguous range of the read index; every rank runs
-the same kernels on its own reads, one process per GPU.  The only collective is one
-all-reduce of the {raw bytes, compressed bytes, reads} totals (24 bytes, RCCL over xGMI
-on GPUs, gloo in the CPU tests) plus a MAX-reduce of the elapsed time for reporting.
+the same kernels on its own reads, one process per GPU.  The only collective is ONE
+all-gather of {raw bytes, compressed bytes, reads, elapsed microseconds} per rank (32 bytes
+each; RCCL over xGMI on GPUs, gloo in the CPU tests): sums, the slowest rank's time and the
+spread over the ranks all come out of that one exchange.
 """
 import os
 
@@ -44,17 +45,28 @@ def weak_shard(reads_per_rank, rank):
     return rank * reads_per_rank, reads_per_rank
 
 
-def reduce_totals(raw_bytes, comp_bytes, nreads, elapsed_s, device=None):
-    """Sum the byte/read totals and take the slowest rank's time.  No-op when not
-    running under torch.distributed."""
+def gather_totals(raw_bytes, comp_bytes, nreads, elapsed_s, device=None):
+    """THE collective of the path: one all-gather of {raw bytes, compressed bytes, reads, elapsed
+    microseconds} per rank - 32 bytes each, RCCL over xGMI on GPUs, gloo in the CPU tests.  Every rank gets
+    every rank's record, so sums, the slowest rank's time (what bench.py divides by) and the spread over the
+    ranks all come from this one exchange.
+    -> (raw, comp, reads, max elapsed seconds, per-rank list of (raw, comp, reads, seconds))."""
     import torch
     import torch.distributed as dist
 
+    mine = (int(raw_bytes), int(comp_bytes), int(nreads), int(round(float(elapsed_s) * 1e6)))
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return int(raw_bytes), int(comp_bytes), int(nreads), float(elapsed_s)
-    tot = torch.tensor([int(raw_bytes), int(comp_bytes), int(nreads)], dtype=torch.int64, device=device)
-    tmax = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    r, c, n = (int(x) for x in tot.tolist())
-    return r, c, n, float(tmax.item())
+        return mine[0], mine[1], mine[2], mine[3] / 1e6, [(mine[0], mine[1], mine[2], mine[3] / 1e6)]
+    world = dist.get_world_size()
+    send = torch.tensor(mine, dtype=torch.int64, device=device)
+    recv = torch.empty(4 * world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(recv, send)
+    rows = recv.view(world, 4).tolist()
+    per_rank = [(int(r[0]), int(r[1]), int(r[2]), r[3] / 1e6) for r in rows]
+    return (sum(r[0] for r in per_rank), sum(r[1] for r in per_rank), sum(r[2] for r in per_rank),
+            max(r[3] for r in per_rank), per_rank)
+
+
+def reduce_totals(raw_bytes, comp_bytes, nreads, elapsed_s, device=None):
+    """Sum of the byte / read totals and the slowest rank's time (gather_totals without the per-rank rows)."""
+    return gather_totals(raw_bytes, comp_bytes, nreads, elapsed_s, device)[:4]

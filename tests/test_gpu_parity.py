@@ -654,3 +654,61 @@ def test_longest_read_in_a_mixed_batch(oracle):
         back = press.depress_batch_host(m, [st for _, st in ok], [len(r) for r, _ in ok])
         for (r, _), b in zip(ok, back):
             assert b is not None and np.array_equal(b, r), (m, len(r))
+
+
+@pytest.mark.parametrize("m", ["shuffman_vbe21_zd", "svb12_zd"])
+def test_bench_batch_parity(oracle, m):
+    """bench.py's exact batch (seed 20261004, 8192 NA12878-like reads, 0.93 G samples) through press_batch:
+    out_len of EVERY read equals the oracle's stream length (oracle on the host's threads), and the bytes of a
+    256-read sample that includes the 8 longest reads equal the oracle's; depress_batch gives the samples back."""
+    import ctypes
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch
+
+    sys.path.insert(0, _libs.ROOT)
+    import bench
+
+    dev = torch.device("cuda", 0)
+    press.use_torch_stream()
+    b = bench.Batch(torch, press, synth, 20261004, 0, 8192, dev, None)
+    caps, d_out, d_out_off, d_in_off = b.arena(torch, press, m)
+    press.press_batch(m, b.sig, b.d_off, b.d_n, d_out, d_out_off, b.d_len)
+    press.depress_batch(m, d_out, d_in_off, b.d_len, b.d_back, b.d_off, b.d_n, b.d_outn)
+    torch.cuda.synchronize()
+    assert torch.equal(b.d_back, b.sig)
+    lens = b.d_len.cpu().numpy()
+    host = b.sig.cpu().numpy()
+    out_off = d_out_off.cpu().numpy()
+    order = np.argsort(-b.n)
+    sample = set(int(x) for x in order[:8]) | set(int(x) for x in np.random.default_rng(3).choice(8192, 248, replace=False))
+    got_bytes = {}
+    dh = d_out.cpu().numpy()
+    for r in sample:
+        got_bytes[r] = dh[int(out_off[r]): int(out_off[r]) + int(lens[r])].tobytes()
+    del dh
+    mid = _libs.METHODS[m]
+    want_len = np.zeros(8192, dtype=np.int64)
+    bad = []
+
+    def work(chunk):
+        cap = int(max(oracle.bound(mid, int(b.n[r])) for r in chunk)) + 1024
+        out = np.zeros(cap + 64, dtype=np.uint8)
+        for r in chunk:
+            s = host[int(b.starts[r]): int(b.starts[r]) + int(b.n[r])]
+            nout = ctypes.c_uint64(cap)
+            ret = oracle._press(mid, s.ctypes.data, s.size, out.ctypes.data, ctypes.byref(nout))
+            assert ret == 0
+            want_len[r] = nout.value
+            if r in sample and out[: nout.value].tobytes() != got_bytes[r]:
+                bad.append(r)
+
+    nthr = max(1, min(len(os.sched_getaffinity(0)), 32))
+    # longest reads first, dealt out round-robin: the threads finish together
+    chunks = [[int(x) for x in order[t::nthr * 8]] for t in range(nthr * 8)]
+    with ThreadPoolExecutor(nthr) as ex:
+        list(ex.map(work, chunks))
+    assert not bad, "stream bytes differ from the oracle's for reads %s" % bad[:8]
+    diff = np.nonzero(want_len != lens)[0]
+    assert diff.size == 0, "out_len differs from the oracle's for %d reads, first %s" % (diff.size, diff[:8])

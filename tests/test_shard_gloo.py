@@ -21,6 +21,33 @@ def _free_port():
     return p
 
 
+def _worker_by_samples(rank, world, port, total_reads, q):
+    """world_size 4, heavy-tailed read lengths, shards balanced by SAMPLES (shard_range with lengths)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _libs
+    from honours_amd import shard, synth
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, first_samples = synth.read_lengths(91, 0, total_reads)
+    n = np.minimum(n, 40000)  # (the oracle is the stand-in for the kernels: keep it to seconds)
+    first, count = shard.shard_range(total_reads, rank, world, lengths=n)
+    o = _libs.oracle()
+    raw = comp = 0
+    for k in range(first, first + count):
+        s = synth.synth_read(91, k, int(n[k]), int(first_samples[k]))
+        ret, c = o.press("hasgam_vbsse21_zdq", s)
+        assert ret == 0
+        raw += 2 * s.size
+        comp += len(c)
+    tot = shard.gather_totals(raw, comp, count, 0.5 + 0.25 * rank)
+    q.put((rank, first, count, raw, tot))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, total_reads, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -69,6 +96,38 @@ def test_two_rank_shard_and_reduce():
     for r in res:
         assert r[3:6] == (2 * int(off[-1]), comp, total_reads)
         assert r[6] == 2.0  # MAX over ranks of (1.0 + rank)
+
+
+def test_four_rank_shard_by_samples_and_gather():
+    """world_size 4 on heavy-tailed lengths: shards by sample totals, ONE all-gather carries sums, the slowest
+    rank's time and every rank's own record"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from honours_amd import shard, synth
+
+    total_reads, world = 48, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_by_samples, args=(r, world, port, total_reads, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, _ = synth.read_lengths(91, 0, total_reads)
+    n = np.minimum(n, 40000)
+    # contiguous, disjoint, complete; about equal samples
+    assert res[0][1] == 0 and sum(r[2] for r in res) == total_reads
+    for a, b in zip(res, res[1:]):
+        assert a[1] + a[2] == b[1]
+    per = [r[3] for r in res]
+    assert max(abs(x - 2 * int(n.sum()) / world) for x in per) <= 2 * int(n.max())
+    for r in res:
+        raw, comp, reads, tmax, rows = r[4]
+        assert raw == 2 * int(n.sum()) and reads == total_reads and comp == sum(x[1] for x in rows)
+        assert tmax == 1.25 and [x[3] for x in rows] == [0.5, 0.75, 1.0, 1.25]
+        assert [x[0] for x in rows] == per and [x[2] for x in rows] == [q[2] for q in res]
 
 
 def test_shard_range_balanced():
