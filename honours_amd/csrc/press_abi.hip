@@ -99,6 +99,7 @@ struct Ctx {
 	uint32_t zs_nhost = 0; // frames the last zstd depress batch left to libzstd
 	// static Huffman table currently on the device
 	bool have_table = false;
+	bool table_trie = false; // some code of the table is beyond the second-level tables (HUF_NEEDS_TRIE)
 	uint32_t tlen[256];
 	uint64_t tbits[256];
 
@@ -227,6 +228,7 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 	HuffDev &h = hv[0];
 	memset(&h, 0xFF, sizeof h); // lut = 0xFFFF, child/leaf = -1
 	int nnodes = 1, ncoded = 0;
+	bool needs_trie = false;
 	for (int s = 0; s < 256; s++) {
 		const uint32_t l = len[s];
 		if (l > 24) // huffman.c takes codes of up to 255 bits; the device tables stop at 24 (press_hip.h)
@@ -303,6 +305,18 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 			for (uint32_t i = rest; i < (1u << depth[id]); i += 1u << rl)
 				h.lut2[h.l2off[id] + i] = (uint16_t) (s | (len[s] << 8));
 		}
+		// does any code need the trie (a long code whose prefix got no second-level table)?  If none does, the
+		// kernels run without it (their TRIE = false variants) and a prefix that is no code at all points at a
+		// second-level slot that says so
+		needs_trie = used > HUF_L2_NONE; // (the slot must be free)
+		for (int s = 0; s < 256; s++) {
+			if (len[s] <= (uint32_t) HUF_LUT_BITS)
+				continue;
+			const int pfx = (int) (bits[s] & ((1u << HUF_LUT_BITS) - 1));
+			const int id = id_of[pfx];
+			if (id < 0 || h.lut[pfx] != (uint16_t) (0x8000u | (uint32_t) id))
+				needs_trie = true;
+		}
 		for (int i = 0; i < HUF_L2_ENTRIES; i++) {
 			const uint32_t e2 = h.lut2[i];
 			h.l2ld[i] = e2 == 0xFFFFu ? (uint16_t) 0xFFFFu : (uint16_t) ((e2 >> 8) | ((unzz8(e2 & 0xFFu) & 0xFFu) << 8));
@@ -312,7 +326,7 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 	for (uint32_t i = 0; i < (1u << HUF_LUT_BITS); i++) {
 		const uint16_t e1 = h.lut[i];
 		if (e1 == 0xFFFFu) {
-			h.lut32[i] = 0xFFFFFFFFu;
+			h.lut32[i] = needs_trie ? 0xFFFFFFFFu : (HUF_LONG | HUF_L2_NONE);
 		} else if (e1 & 0x8000u) { // a long code's prefix: where its second-level table sits
 			const uint32_t id = e1 & 0xFFu;
 			h.lut32[i] = HUF_LONG | ((uint32_t) h.l2bits[id] << 12) | h.l2off[id];
@@ -352,7 +366,10 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 		else if (e0 != 0xFFFFu && (e0 & 0x8000u)) // long code: second-level table of lengths and deltas
 			h.mlut[i] = HUF_MLONG | (uint32_t) h.l2off[e0 & 0xFFu] | ((uint32_t) h.l2bits[e0 & 0xFFu] << 12);
 		else
-			h.mlut[i] = 0xFFFFFFFFu;
+			h.mlut[i] = needs_trie ? 0xFFFFFFFFu : (HUF_MLONG | HUF_L2_NONE);
+		// the accumulator form (k_huf_sync's lean loop) and the first code alone (its careful loop)
+		h.alut[i] = n ? (pos | (n << HUF_A_CNT) | (((uint32_t) dsum & 0x7FFFu) << HUF_A_SUM)) : h.mlut[i];
+		h.flut[i] = n ? (uint16_t) (len1 | (((uint32_t) d1 & 0xFFu) << 8)) : (uint16_t) 0;
 	}
 	if (!ncoded)
 		return fail(PRESS_HIP_EARG, "Huffman table: no symbol has a code");
@@ -369,6 +386,7 @@ int upload_table(const uint32_t len[256], const uint64_t bits[256])
 	HIPCHK(hipMemcpy(g.huff.p, &h, sizeof h, hipMemcpyHostToDevice));
 	memcpy(g.tlen, len, sizeof g.tlen);
 	memcpy(g.tbits, bits, sizeof g.tbits);
+	g.table_trie = needs_trie;
 	g.have_table = true;
 	return 0;
 }
@@ -1234,7 +1252,7 @@ extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint
 		a.hmin = (uint32_t *) g.hmin.p;
 		a.max_htiles = max_htiles_of(total_samples, nreads);
 		a.hlist_cap = (uint32_t) hlist_cap_of(a.max_htiles);
-		a.huf_minlen = table_minlen();
+		a.huf_minlen = table_minlen() | (g.table_trie ? HUF_NEEDS_TRIE : 0u);
 	}
 
 	if (device_resident) {

@@ -50,8 +50,36 @@
 
 #include "press_internal.h"
 #include "press_packed.h"
+#include <type_traits>
 
 namespace ph {
+
+#ifdef HUF_STAMPS
+// diagnostic build only (tools/hufstamps.py): where a wave of k_huf_sync / k_huf_emit spends its time - s_memtime
+// differences of lane 0, summed per phase over all units
+__device__ unsigned long long g_hstamp[32];
+#define HSTAMP_DECL                                             \
+	unsigned long long hs_t = __builtin_amdgcn_s_memtime(); \
+	unsigned long long hs_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
+#define HSTAMP(i)                                                              \
+	do { /* (per wave, in scalar registers; flushed once at the end) */    \
+		__builtin_amdgcn_sched_barrier(0);                             \
+		const unsigned long long hs_n = __builtin_amdgcn_s_memtime(); \
+		hs_acc[(i) & 7] += hs_n - hs_t;                                \
+		hs_t = hs_n;                                                   \
+		__builtin_amdgcn_sched_barrier(0);                             \
+	} while (0)
+#define HSTAMP_FLUSH(base)                                                     \
+	do {                                                                   \
+		if ((threadIdx.x & 63) == 0)                                   \
+			for (int hs_i = 0; hs_i < 8; hs_i++)                   \
+				atomicAdd(&g_hstamp[(base) + hs_i], hs_acc[hs_i]); \
+	} while (0)
+#else
+#define HSTAMP_DECL
+#define HSTAMP(i)
+#define HSTAMP_FLUSH(base)
+#endif
 
 constexpr uint32_t HEND = 0xFFFFFFFFu; // "no further code": end of input or an undecodable prefix
 constexpr uint32_t R_END = 31;         // the same in a record's position fields
@@ -146,80 +174,108 @@ __device__ __forceinline__ void col_load(uint32_t *col, const uint8_t *src, int3
 // the delta a one-byte value stands for (zig-zag undone)
 __device__ __forceinline__ int32_t unzz8(uint32_t z) { return (int32_t) (z >> 1) ^ -(int32_t) (z & 1u); }
 
+// LDS through 32-bit pointers: address arithmetic stays in 32 bits (generic pointers made the compiler compute every
+// row address with a 64-bit multiply-add, a quarter-rate instruction in the innermost loop)
+typedef __attribute__((address_space(3))) const uint32_t *lds_cu32p;
+typedef __attribute__((address_space(3))) const uint16_t *lds_cu16p;
+typedef __attribute__((address_space(3))) const uint8_t *lds_cu8p;
+typedef __attribute__((address_space(3))) uint8_t *lds_u8p;
+
+// the tables of the length scans, in LDS (k_huf_sync, k_huf_fix, k_huf_serial)
+struct LenTabs {
+	alignas(16) uint32_t alut[1 << HUF_LUT_BITS];
+	alignas(16) uint16_t flut[1 << HUF_LUT_BITS];
+	alignas(16) uint16_t l2ld[HUF_L2_ENTRIES];
+};
+
 // Count the codes that start in [start, lim) of a column (bit positions relative to the column),
 // stopping at the payload end nb, and sum the deltas their symbols stand for (dsum, mod 2^16);
 // returns where the next code starts, or HEND.
-// mlut entry (HuffDev::mlut): total bits | codes << 4 | bits of the first code << 8 | its delta << 12 |
-// sum of the deltas << 20 of every whole code that fits in 12 bits; long codes (13 .. 24 bits: one code
-// in 200 of the NA12878 table, one look-up in four has such a lane) through the second-level table.
-template <int S = 64>
-__device__ __forceinline__ uint32_t len_scan(const uint32_t *col, const uint32_t *mlut, const uint16_t *l2ld,
-					     const HuffDev *hd, uint32_t start, uint32_t lim, uint32_t nb, uint32_t &cnt,
-					     uint32_t &dsum)
+// The lean loop keeps position, count and sum in ONE register, A = (position + 30) | codes << 9 | sum << 16, and
+// the table entry (HuffDev::alut) is the increment of all three for every whole code that fits in 12 bits: a step is
+// position test, row address, the two dwords around the position (read from the column at every step - no register
+// window to shift), funnel shift, table look-up, one add, the long-code test: 8 vector instructions (the version
+// with separate counters, field extraction and a register window over the column took 19).  The position is kept 30
+// bits ahead so that the funnel shift leaves the 12 window bits at bits 2 .. 13: masked, they are the table's byte
+// offset.  Long codes (13 .. 24 bits: one code in 200 of the NA12878 table, one look-up in four has such a lane)
+// through the second-level table; the last codes in front of the limit take the careful loop (first code alone:
+// HuffDev::flut).
+template <bool TRIE, int S = 64>
+__device__ __forceinline__ uint32_t len_scan(const uint32_t *col_, const LenTabs *tabs, const HuffDev *hd, uint32_t start,
+					     uint32_t lim, uint32_t nb, uint32_t &cnt, uint32_t &dsum)
 {
+	const lds_cu32p col = (lds_cu32p) col_;
+	const lds_cu32p alut = (lds_cu32p) tabs->alut;
+	const lds_cu16p flut = (lds_cu16p) tabs->flut;
+	const lds_cu16p l2ld = (lds_cu16p) tabs->l2ld;
 	bool bad = start == HEND;
-	uint32_t p = bad ? 0u : start;
 	uint32_t L = lim < nb ? lim : nb; // codes must START below this
 	if (bad)
 		L = 0;
-	uint32_t c = 0;
-	int32_t d = 0;
-	// a long code: bits | delta << 8; 0: the bits are no code
+	// a long code: bits | delta << 8; 0: the bits are no code.  wnd: the stream bits from the code's first on
+	// (TRIE: only for tables with codes the second-level tables do not hold - the host knows (HuffDev::needs_trie);
+	// without it no entry is 0xFFFFFFFF: prefixes that are no code point at a second-level slot that says so)
 	auto long_ld = [&](uint32_t e, uint32_t wnd) -> uint32_t {
-		if (e == 0xFFFFFFFFu) { // beyond the second level: the trie in global memory
+		if (TRIE && e == 0xFFFFFFFFu) { // beyond the second level: the trie in global memory
 			const uint32_t t = trie_code(hd, wnd);
 			return t ? (((t >> 24) & 31u) | (((uint32_t) unzz8(t & 0xFFu) & 0xFFu) << 8)) : 0u;
 		}
 		const uint32_t v = l2ld[(e & 0xFFFu) + ((wnd >> HUF_LUT_BITS) & ((1u << ((e >> 12) & 15u)) - 1u))];
 		return v == 0xFFFFu ? 0u : v;
 	};
+	constexpr uint32_t PB = 30; // the position's bias
+	const lds_cu32p colm = col - S;
+	uint32_t A = (bad ? 0u : start) + PB;
 	{
-		int32_t Lm = (int32_t) L - HUF_LUT_BITS; // every code of a look-up starts below L while p <= Lm
-		uint32_t j = p >> 5;
-		uint32_t w0 = col[j * S], w1 = col[(j + 1) * S];
-		for (;;) {
-			const bool act = (int32_t) p <= Lm;
-			if (!any64(act))
-				break;
-			if (act) { // (exec-masked body: the lanes that are done do nothing)
-				const uint32_t w2 = col[(j + 2) * S]; // (the row behind the last column keeps this read inside the array)
-				const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p); // shift = p & 31
-				const uint32_t e = mlut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
-				uint32_t tot = e & 15u, n = (e >> 4) & 15u;
-				int32_t dd = (int32_t) (e << 1) >> 21;
+		int32_t LmP = (int32_t) L - HUF_LUT_BITS + (int32_t) PB; // every code of a look-up starts below L while p <= L - 12
+		// the two dwords around the (biased) position stay in registers; the dword behind them is fetched while the
+		// look-up is in flight (one LDS round trip per step on the chain of dependent operations, not two)
+		uint32_t jj = (A >> 5) & 15u;
+		uint32_t w0 = colm[__umul24(jj, (uint32_t) S)], w1 = colm[__umul24(jj, (uint32_t) S) + S];
+		// (a divergent loop: a lane that is through leaves it - the lanes still in it are the execution mask, which
+		// only shrinks; written as "all lanes loop while any is active, the body under a condition" the compiler
+		// spent a dozen scalar instructions per step on masks)
+		while ((int32_t) (A & 0x1FFu) <= LmP) {
+			const uint32_t pp = A & 0x1FFu;
+			{
+				const uint32_t w2 = colm[__umul24(jj, (uint32_t) S) + 2 * S];
+				const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, A); // shift = pp & 31; window bits at 2 .. 13
+				const uint32_t e = *(lds_cu32p) ((lds_cu8p) alut + (wnd & (((1u << HUF_LUT_BITS) - 1u) << 2)));
+				uint32_t inc = e;
 				if ((int32_t) e < 0) { // rare (one code in 200): a long code, or none
-					const uint32_t ld = long_ld(e, wnd);
-					tot = ld & 0xFFu;
-					n = 1;
-					dd = (int32_t) (int8_t) (ld >> 8);
-					if (tot == 0 || p + tot > L) { // no code, or it ends behind the limit:
-						tot = n = 0;           // the careful loop decides
-						dd = 0;
-						Lm = -1;
+					const uint32_t ld = long_ld(e, wnd >> 2);
+					const uint32_t tot = ld & 0xFFu;
+					inc = tot | (1u << HUF_A_CNT) | (((uint32_t) (int32_t) (int8_t) (ld >> 8) & 0x7FFFu) << HUF_A_SUM);
+					if (tot - 1u >= L + PB - pp) { // no code (tot 0), or it ends behind the limit (tot > L - p):
+						inc = 0;               // the careful loop decides
+						LmP = -1;
 					}
 				}
-				p += tot;
-				c += n;
-				d += dd;
-				const uint32_t jn = p >> 5; // a step crosses at most one dword
-				if (jn != j) {
+				A += inc;
+				const uint32_t jn = (A >> 5) & 15u; // a step crosses at most one dword
+				if (jn != jj) {
 					w0 = w1;
 					w1 = w2;
 				}
-				j = jn;
+				jj = jn;
 			}
 		}
 	}
+	uint32_t p = (A & 0x1FFu) - PB;
+	uint32_t c = (A >> HUF_A_CNT) & 0x7Fu;
+	int32_t d = (int32_t) (A << 1) >> 17; // bits 16 .. 30, signed
 	for (;;) {
 		const bool act = p < L;
 		if (!any64(act))
 			break;
 		const uint32_t pp = act ? p : 0u;
 		const uint32_t j = pp >> 5;
-		const uint32_t wnd = __builtin_amdgcn_alignbit(col[(j + 1) * S], col[j * S], pp);
-		const uint32_t e = mlut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
-		uint32_t tot = e & 15u, n = (e >> 4) & 15u, len1 = (e >> 8) & 15u;
-		int32_t dall = (int32_t) (e << 1) >> 21, d1 = (int32_t) (e << 12) >> 24;
+		const int r0 = (int) __umul24(j, (uint32_t) S);
+		const uint32_t wnd = __builtin_amdgcn_alignbit(col[r0 + S], col[r0], pp);
+		const uint32_t e = alut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
+		const uint32_t f = flut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
+		uint32_t tot = e & 15u, n = (e >> HUF_A_CNT) & 15u, len1 = f & 0xFFu;
+		int32_t dall = (int32_t) (e << 1) >> 17, d1 = (int32_t) (int8_t) (f >> 8);
 		bool fail = false;
 		if (any64(act && (int32_t) e < 0)) {
 			if (act && (int32_t) e < 0) {
@@ -301,14 +357,18 @@ __device__ __forceinline__ void list_push(uint32_t *list, uint32_t *cnt, uint32_
 		list[idx] = value;
 }
 
-__device__ __forceinline__ void load_len_tables(const HuffDev *hd, uint32_t *mlut, uint16_t *l2ld, uint32_t nthr)
+__device__ __forceinline__ void load_len_tables(const HuffDev *hd, LenTabs *t, uint32_t nthr)
 {
-	const uint4 *s4 = reinterpret_cast<const uint4 *>(hd->mlut);
-	uint4 *d4 = reinterpret_cast<uint4 *>(mlut);
+	const uint4 *s4 = reinterpret_cast<const uint4 *>(hd->alut);
+	uint4 *d4 = reinterpret_cast<uint4 *>(t->alut);
 	for (uint32_t i = threadIdx.x; i < (1u << HUF_LUT_BITS) / 4; i += nthr)
 		d4[i] = s4[i];
+	const uint4 *f4 = reinterpret_cast<const uint4 *>(hd->flut);
+	uint4 *g4 = reinterpret_cast<uint4 *>(t->flut);
+	for (uint32_t i = threadIdx.x; i < (1u << HUF_LUT_BITS) / 8; i += nthr)
+		g4[i] = f4[i];
 	const uint4 *t4 = reinterpret_cast<const uint4 *>(hd->l2ld);
-	uint4 *u4 = reinterpret_cast<uint4 *>(l2ld);
+	uint4 *u4 = reinterpret_cast<uint4 *>(t->l2ld);
 	for (uint32_t i = threadIdx.x; i < (uint32_t) HUF_L2_ENTRIES / 8; i += nthr)
 		u4[i] = t4[i];
 }
@@ -321,19 +381,24 @@ __device__ __forceinline__ void load_len_tables(const HuffDev *hd, uint32_t *mlu
 // subsequence in front of it ended another wave knows (k_huf_fix drops the entry if the guess was right).  Nothing
 // is repaired here.  Units are drawn from a ticket (as in k_huf_emit); list slots are taken LIST_CHUNK at a time
 // per wave (an atomic per push - 400 000 on one counter - tripled this kernel's time), unused ones hold LIST_NONE.
-template <int RU>
+template <int RU, bool TRIE>
 __global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(DecodeArgs a)
 {
 	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW;
 	constexpr int RUNUP = OWN * HUF_RUNUP_EIGHTHS / 8; // bits of the run-up (the last RUNUP bits of the subsequence in front)
 	constexpr int S = SYNC_S;
-	__shared__ __attribute__((aligned(16))) uint32_t lut[1 << HUF_LUT_BITS];
-	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
-	// a wave's image: row j = dword j of [the subsequence in front, lane 0 .. lane 63]; two rows behind the last for
-	// len_scan's look-ahead
-	__shared__ uint32_t imgs[WGS / 64][(NDW + 2) * S];
+	// the tables, then a wave's image: row j = dword j of [the subsequence in front, lane 0 .. lane 63]; two rows behind
+	// the last (len_scan reads the row behind a position's, and a code may reach 23 bits past the subsequence).  One
+	// struct: len_scan also reads the row IN FRONT of a position's (the biased position) - for row 0 that is the
+	// image in front, for the first image the tables: anything, as long as it is the workgroup's LDS
+	struct Lds {
+		LenTabs tabs;
+		uint32_t imgs[WGS / 64][(NDW + 2) * S];
+	};
+	__shared__ __attribute__((aligned(16))) Lds lds;
 	__shared__ unsigned long long s_chunk[64];
 	__shared__ uint32_t s_ticket;
+	auto &imgs = lds.imgs;
 
 	const uint32_t n = min(uniform(a.ctl->nchunks), a.max_htiles);
 	const uint32_t nunits = n * (HT / 64);
@@ -342,7 +407,7 @@ __global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(Decod
 		s_ticket = 0;
 	if (threadIdx.x < 64)
 		s_chunk[threadIdx.x] = ~0ull;
-	load_len_tables(a.huff, lut, lut2, WGS);
+	load_len_tables(a.huff, &lds.tabs, WGS);
 	__syncthreads(); // the tables: the only barrier
 	uint32_t *img = imgs[threadIdx.x >> 6];
 	for (uint32_t i = lane; i < 2 * S; i += 64)
@@ -350,6 +415,7 @@ __global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(Decod
 	uint32_t *col = img + 1 + lane;
 	const uint32_t *rcol = img + lane; // the left neighbour's column
 	uint32_t lpos = 0, lend = 0;       // the wave's chunk of the list: next free slot, end
+	HSTAMP_DECL;
 	for (;;) {
 		uint32_t u = 0;
 		if (lane == 0) {
@@ -370,6 +436,7 @@ __global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(Decod
 		u = uniform(u);
 		if (u >= nunits)
 			break;
+		HSTAMP(0); // ticket
 		const uint32_t k = u / (HT / 64);
 		const uint32_t tid = (u % (HT / 64)) * 64 + lane; // the lane's subsequence of the tile
 		const HufTile *dp = a.htiles + k;
@@ -384,6 +451,7 @@ __global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(Decod
 		if (lane == 0 && !exact) // the bits in front of the unit belong to the same payload (maybe to the tile in front)
 			col_load<NDW, S>(img, src, (int32_t) tid * (OWN / 8) - (OWN / 8), tid ? 0 : -(OWN / 8), nby);
 		wave_lds_sync(); // columns (a lane's run-up reads its neighbour's)
+		HSTAMP(1); // descriptor + payload loads
 		// payload end in the coordinates of the own / the neighbour's column
 		const uint32_t nb = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN);
 		const uint32_t nbr = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN + OWN);
@@ -392,14 +460,16 @@ __global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(Decod
 		const bool first_known = lane == 0 && exact;
 		uint32_t f, c0, c, dz, dv;
 		{
-			const uint32_t g = len_scan<S>(rcol, lut, lut2, a.huff, first_known ? HEND : (uint32_t) (OWN - RUNUP), OWN, nbr, c0, dz);
+			const uint32_t g = len_scan<TRIE, S>(rcol, &lds.tabs, a.huff, first_known ? HEND : (uint32_t) (OWN - RUNUP), OWN, nbr, c0, dz);
 			f = g == HEND ? HEND : g - OWN;
 			if (g == HEND && nb > 0)
 				f = 0; // the guess ran into a bit pattern that is no code: any guess will do
 			if (first_known)
 				f = 0;
 		}
-		const uint32_t e = len_scan<S>(col, lut, lut2, a.huff, f, OWN, nb, c, dv);
+		HSTAMP(2); // run-up
+		const uint32_t e = len_scan<TRIE, S>(col, &lds.tabs, a.huff, f, OWN, nb, c, dv);
+		HSTAMP(3); // own pass
 		const uint32_t e8 = e == HEND ? R_END : e - OWN;
 		const uint32_t cw = wave_scan(c), dw = wave_scan(dv);
 		a.hrec[(uint64_t) k * HT + tid] = pack_rec(f, c, dv);
@@ -431,7 +501,9 @@ __global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(Decod
 					a.hlist[idx] = k * HT + tid;
 			}
 		}
+		HSTAMP(4); // records, list
 	}
+	HSTAMP_FLUSH(0);
 	for (uint32_t j = lpos + lane; j < lend && j < a.hlist_cap; j += 64) // what is left of the wave's last chunk
 		a.hlist[j] = LIST_NONE;
 }
@@ -444,13 +516,16 @@ __global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(Decod
 #define HUF_FIX_WG 1024
 #endif
 constexpr int FIX_WG = HUF_FIX_WG; // waves that are each on their own share the tables
-template <int RU>
+template <int RU, bool TRIE>
 __global__ __launch_bounds__(FIX_WG) void k_huf_fix(DecodeArgs a, int round, int last)
 {
 	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW, NCOL = HufGeo<RU>::NCOL;
-	__shared__ __attribute__((aligned(16))) uint32_t lut[1 << HUF_LUT_BITS];
-	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
-	__shared__ uint32_t imgs[FIX_WG / 64][NCOL * 64 + 64];
+	struct Lds { // (one struct: see k_huf_sync)
+		LenTabs tabs;
+		uint32_t imgs[FIX_WG / 64][NCOL * 64 + 64];
+	};
+	__shared__ __attribute__((aligned(16))) Lds lds;
+	auto &imgs = lds.imgs;
 
 	const uint32_t *in_list = a.hlist + (round & 1 ? a.hlist_cap : 0u);
 	uint32_t *out_list = a.hlist + (round & 1 ? 0u : a.hlist_cap);
@@ -460,7 +535,8 @@ __global__ __launch_bounds__(FIX_WG) void k_huf_fix(DecodeArgs a, int round, int
 	if ((uint32_t) FIX_WG * blockIdx.x >= n)
 		return;
 	const uint32_t lane = threadIdx.x & 63;
-	load_len_tables(a.huff, lut, lut2, FIX_WG);
+	load_len_tables(a.huff, &lds.tabs, FIX_WG);
+	__syncthreads(); // the tables are loaded by all waves together (every wave of the workgroup gets here: the early return is per workgroup)
 	uint32_t *col = imgs[threadIdx.x >> 6] + lane;
 	for (uint32_t i0 = FIX_WG * blockIdx.x + (threadIdx.x & ~63u); i0 < n; i0 += (uint32_t) FIX_WG * gridDim.x) {
 		uint32_t ent = i0 + lane < n ? in_list[i0 + lane] : LIST_NONE;
@@ -481,7 +557,7 @@ __global__ __launch_bounds__(FIX_WG) void k_huf_fix(DecodeArgs a, int round, int
 		const uint32_t pe = mine ? a.hend[g - 1] : R_END;
 		const uint32_t old_e = mine ? a.hend[g] : R_END;
 		uint32_t c2, d2;
-		const uint32_t e2 = len_scan(col, lut, lut2, a.huff, (!mine || pe == R_END) ? HEND : pe, OWN,
+		const uint32_t e2 = len_scan<TRIE>(col, &lds.tabs, a.huff, (!mine || pe == R_END) ? HEND : pe, OWN,
 					     clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN), c2, d2);
 		const uint32_t e8 = e2 == HEND ? R_END : e2 - OWN;
 		bool next = false;
@@ -510,13 +586,16 @@ __global__ __launch_bounds__(FIX_WG) void k_huf_fix(DecodeArgs a, int round, int
 // What k_huf_fix's rounds left (a code whose lengths share a factor never synchronises; an ordinary table is
 // through after two rounds): one wave per marked read walks its subsequences from the first unsettled one,
 // serially - slow and always right.
-template <int RU>
+template <int RU, bool TRIE>
 __global__ __launch_bounds__(64) void k_huf_serial(DecodeArgs a)
 {
 	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW, NCOL = HufGeo<RU>::NCOL;
-	__shared__ __attribute__((aligned(16))) uint32_t lut[1 << HUF_LUT_BITS];
-	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
-	__shared__ uint32_t img[NCOL * 64 + 64];
+	struct Lds { // (one struct: see k_huf_sync)
+		LenTabs tabs;
+		uint32_t img[NCOL * 64 + 64];
+	};
+	__shared__ __attribute__((aligned(16))) Lds lds;
+	auto &img = lds.img;
 
 	const uint32_t r = blockIdx.x;
 	const uint32_t g0 = uniform(a.hmin[r]);
@@ -524,7 +603,7 @@ __global__ __launch_bounds__(64) void k_huf_serial(DecodeArgs a)
 		return;
 	const uint32_t lane = threadIdx.x;
 	const uint32_t k0 = uniform(a.hread[2 * r]), nt = uniform(a.hread[2 * r + 1]);
-	load_len_tables(a.huff, lut, lut2, 64);
+	load_len_tables(a.huff, &lds.tabs, 64);
 	uint32_t *col = img + lane;
 	const uint64_t gend = (uint64_t) (k0 + nt) * HT;
 	for (uint64_t g = g0; g < gend; g++) {
@@ -542,7 +621,7 @@ __global__ __launch_bounds__(64) void k_huf_serial(DecodeArgs a)
 			col_load<NDW>(col, a.in + dp->src, (int32_t) tid * (OWN / 8), 0, (int32_t) ((nbits_t + 7) >> 3));
 		wave_lds_sync();
 		uint32_t c2, d2;
-		const uint32_t e2 = len_scan(col, lut, lut2, a.huff, (lane || pe == R_END) ? HEND : pe, OWN,
+		const uint32_t e2 = len_scan<TRIE>(col, &lds.tabs, a.huff, (lane || pe == R_END) ? HEND : pe, OWN,
 					     clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN), c2, d2);
 		if (lane == 0) {
 			a.hrec[g] = pack_rec(pe == R_END ? HEND : pe, c2, d2);
@@ -658,55 +737,68 @@ constexpr uint32_t EMIT_STG = 3328; // staging bytes per wave: 52 per lane (NA12
 // signed byte) to wp[0 ..] (LDS staging or the one-byte stream's place).  k_huf_sync counted the codes that
 // start in the subsequence, so the count alone ends the loop: no position is checked against the end.
 // lut entry (HuffDev::lut32): d1 | adv << 8 | d2 << 16 | len1 << 24 | HUF_TWO; long codes through lut2.
-template <typename WP>
-__device__ __forceinline__ void emit_codes(const uint32_t *col, const uint32_t *lut, const uint16_t *lut2,
-					   const HuffDev *hd, uint32_t p, uint32_t nmine, WP wp)
+// A step: room test, row address, the two dwords around the position (read from the column at every step), funnel
+// shift, look-up, long-code test, two byte stores, position and output pointer moved on - 10 vector instructions
+// (19 + a 64-bit multiply-add with a register window over the column, a conditional second store and a symbol
+// counter).  Both bytes of an entry are always stored: while the count has room for two, the second slot is the
+// lane's own, and a one-code entry's second byte is overwritten by the lane's next store.  The position runs 30 bits
+// ahead, so that the window bits sit at bits 2 .. 13 of the funnel shift: masked, they are the table's byte offset.
+template <bool TRIE, bool LDSOUT>
+__device__ __forceinline__ void emit_codes(const uint32_t *col_, const uint32_t *lut_, const uint16_t *lut2_,
+					   const HuffDev *hd, uint32_t p, uint32_t nmine, uint8_t *wp_)
 {
+	const lds_cu32p col = (lds_cu32p) col_;
+	const lds_cu8p lut = (lds_cu8p) lut_;
+	const lds_cu16p lut2 = (lds_cu16p) lut2_;
 	// a long code (13 .. 24 bits) as a one-code entry; 0: the bits are no code (cannot come up among
-	// the codes k_huf_sync counted)
+	// the codes k_huf_sync counted).  wnd: the stream bits from the code's first on
 	auto long_entry = [&](uint32_t e, uint32_t wnd) -> uint32_t {
-		if (e == 0xFFFFFFFFu) {
+		if (TRIE && e == 0xFFFFFFFFu) {
 			const uint32_t t = trie_code(hd, wnd);
 			return t ? ((t & 0xFFFFFF00u) | ((uint32_t) unzz8(t & 0xFFu) & 0xFFu)) : 0u;
 		}
 		const uint32_t e2 = lut2[(e & 0xFFFu) + ((wnd >> HUF_LUT_BITS) & ((1u << ((e >> 12) & 15u)) - 1u))];
 		return e2 == 0xFFFFu ? 0u : (((uint32_t) unzz8(e2 & 0xFFu) & 0xFFu) | (e2 & 0x1F00u) | ((e2 & 0x1F00u) << 16));
 	};
-	uint32_t q = 0; // symbols written
-	uint32_t j = p >> 5;
-	uint32_t w0 = col[j * 64], w1 = col[(j + 1) * 64];
-	for (;;) { // while the count has room for two
-		const bool act = q + 2 <= nmine;
-		if (!any64(act))
-			break;
-		if (act) { // (exec-masked body: the lanes that are done do nothing)
-			const uint32_t w2 = col[(j + 2) * 64]; // (the row behind the last column keeps this read inside the array)
-			const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p);
-			uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
+	typedef typename std::conditional<LDSOUT, lds_u8p, uint8_t *>::type WP;
+	WP w = (WP) wp_;
+	const WP wend = w + nmine;
+	WP wlim = nmine ? wend - 1 : w; // a step needs room for two: w < wlim
+	constexpr uint32_t PB = 30;
+	const lds_cu32p colm = col - 64;
+	uint32_t pp = p + PB;
+	uint32_t jj = pp >> 5;
+	uint32_t w0 = colm[__umul24(jj, 64u)], w1 = colm[__umul24(jj, 64u) + 64];
+	while (w < wlim) { // while the count has room for two (a divergent loop: the lanes that are through leave it)
+		{
+			const uint32_t w2 = colm[__umul24(jj, 64u) + 128]; // the dword behind the window: on its way during the look-up
+			const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, pp);
+			uint32_t e = *(lds_cu32p) (lut + (wnd & (((1u << HUF_LUT_BITS) - 1u) << 2)));
 			if (e >= HUF_LONG) { // rare (one code in 200): longer than 12 bits
-				e = long_entry(e, wnd);
-				if (e == 0)
-					nmine = q; // (cannot happen: stop rather than spin)
+				e = long_entry(e, wnd >> 2);
+				if (e == 0) // (cannot happen: stop rather than spin)
+					wlim = w;
 			}
-			wp[q] = (uint8_t) e;
-			if (e & HUF_TWO)
-				wp[q + 1] = (uint8_t) (e >> 16);
-			q += 1u + ((e >> 29) & 1u);
-			p += (e >> 8) & 0x1Fu;
-			const uint32_t jn = p >> 5;
-			if (jn != j) {
+			w[0] = (uint8_t) e;
+			w[1] = (uint8_t) (e >> 16);
+			w += 1u + ((e >> 29) & 1u);
+			pp += (e >> 8) & 0x1Fu;
+			if (e == 0) // (wlim == w: the loop is over, and so is the lane)
+				w = wlim = wend;
+			const uint32_t jn = pp >> 5; // a step crosses at most one dword
+			if (jn != jj) {
 				w0 = w1;
 				w1 = w2;
 			}
-			j = jn;
+			jj = jn;
 		}
 	}
-	if (q < nmine) { // the last code of an odd count
-		const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, p);
-		uint32_t e = lut[wnd & ((1u << HUF_LUT_BITS) - 1u)];
+	if (w < wend) { // the last code of an odd count
+		const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, pp);
+		uint32_t e = *(lds_cu32p) (lut + (wnd & (((1u << HUF_LUT_BITS) - 1u) << 2)));
 		if (e >= HUF_LONG)
-			e = long_entry(e, wnd);
-		wp[q] = (uint8_t) e;
+			e = long_entry(e, wnd >> 2);
+		w[0] = (uint8_t) e;
 	}
 }
 
@@ -1035,18 +1127,28 @@ struct EmitStg { // the waves' staging buffers; emit_samples16 reads up to 16 by
 	uint8_t post[32];
 };
 
-template <int RU>
+template <int RU, bool TRIE>
 __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 {
 	// (a column here: the NDW dwords that are loaded; emit_codes' look-ahead reads up to two rows further - never
 	// used: the next wave's column, or the pad rows)
 	constexpr int OWN = HufGeo<RU>::OWN, NDW = HufGeo<RU>::NDW, NCOL = HufGeo<RU>::NDW;
 	constexpr uint32_t EW = WGE / 64;
-	__shared__ uint32_t lut[1 << HUF_LUT_BITS];
-	__shared__ __attribute__((aligned(16))) uint16_t lut2[HUF_L2_ENTRIES];
-	__shared__ uint32_t img[EW][NCOL * 64];
-	__shared__ uint32_t pad_row[2 * 64];
-	__shared__ __attribute__((aligned(16))) EmitStg stg_all;
+	// one struct: emit_codes reads the row in front of a position's and the row behind it - for a wave's first / last
+	// row that is the image next to it, the tables or the pad row: anything, as long as it is the workgroup's LDS
+	struct Lds {
+		alignas(16) uint32_t lut[1 << HUF_LUT_BITS];
+		alignas(16) uint16_t lut2[HUF_L2_ENTRIES];
+		uint32_t img[EW][NCOL * 64];
+		uint32_t pad_row[2 * 64];
+		alignas(16) EmitStg stg_all;
+	};
+	__shared__ __attribute__((aligned(16))) Lds lds;
+	auto &lut = lds.lut;
+	auto &lut2 = lds.lut2;
+	auto &img = lds.img;
+	auto &pad_row = lds.pad_row;
+	auto &stg_all = lds.stg_all;
 	// Units (a quarter of a tile each) are handed out one at a time: ten waves do not spread evenly over four SIMDs,
 	// and with a fixed share per wave the kernel lasted as long as the waves of the crowded SIMDs (1.64 instead of
 	// 1.19 ms).  A wave draws a ticket from the workgroup's LDS counter; ticket t is unit t % EMIT_UC of the
@@ -1080,6 +1182,7 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 	__syncthreads(); // the tables; from here on every wave is on its own: columns and staging are private, and
 	                 // what the other waves of its tile hold in front of it comes with the tile's records
 	// persistent workgroups: the tables are loaded once
+	HSTAMP_DECL;
 	for (;;) {
 		uint32_t u = 0;
 		if (lane == 0) {
@@ -1100,6 +1203,7 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 		u = uniform(u);
 		if (u >= nunits)
 			break;
+		HSTAMP(0); // ticket
 		const uint32_t k = u / (HT / 64), k0 = k;
 		const uint32_t tid = (u % (HT / 64)) * 64 + lane; // the lane's subsequence of the tile
 		const bool has = true;
@@ -1120,6 +1224,7 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 		const uint64_t roff = ((uint64_t) uniform(t0.w) << 32) | uniform(t0.z);       // ::low: the read's slot - samples
 		uint8_t *low = a.low + roff;                                                  // in a.sig, one-byte values in a.low, exceptions
 		col_load<NDW>(col, src, (int32_t) tid * (OWN / 8), 0, (int32_t) ((nbits_t + 7) >> 3));
+		HSTAMP(1); // records + payload
 		const uint32_t cnt = (rec >> 8) & 0xFFu;
 		const uint32_t inc = wave_scan(cnt);
 		// HufTRec::base, ::dbase: codes of the read in front of the tile and the sum of their deltas; hwave: the same
@@ -1152,12 +1257,18 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 		// the buffer takes (cannot happen with 5.4-bit codes on average) stores them byte by byte instead
 		// (the read's first exceptions: asked for now, needed behind the decode loop)
 		const uint32_t key = (fused && quota && lane < R.nex) ? R.pos[lane] - lane : 0xFFFFFFFFu;
+		HSTAMP(2); // scan, read record
 		if (wsum <= EMIT_STG) {
-			emit_codes(col, lut, lut2, a.huff, p0, nmine, stg + ex);
+			emit_codes<TRIE, true>(col, lut, lut2, a.huff, p0, nmine, stg + ex);
 			wave_lds_sync();
+			HSTAMP(3); // decode
 			if (fused) {
-				if (quota)
-					emit_samples16(stg, R, emit_plan(R, (uint32_t) obase, quota, B0, lane, key), lane);
+				if (quota) {
+					const EmitPlan P = emit_plan(R, (uint32_t) obase, quota, B0, lane, key);
+					HSTAMP(4); // plan
+					emit_samples16(stg, R, P, lane);
+					HSTAMP(5); // samples
+				}
 			} else {
 				// the one-byte stream, for k_low_decode_chunked: 16-byte stores
 				for (uint32_t o = lane * 16; o < quota; o += 64 * 16) {
@@ -1174,7 +1285,7 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 			}
 			wave_lds_sync(); // staging is free again
 		} else {
-			emit_codes(col, lut, lut2, a.huff, p0, nmine, dst + ex);
+			emit_codes<TRIE, false>(col, lut, lut2, a.huff, p0, nmine, dst + ex);
 			if (fused && quota) {
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the wave reads back what its lanes wrote
 				__builtin_amdgcn_wave_barrier();
@@ -1186,7 +1297,9 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 				}
 			}
 		}
+		HSTAMP(6); // (the rest of a unit)
 	}
+	HSTAMP_FLUSH(8);
 }
 
 // ------------------------------------------------------------------ tiles
@@ -1271,9 +1384,23 @@ __global__ __launch_bounds__(64) void k_huff_tiles(DecodeArgs a)
 #ifndef HUF_FIX_ROUNDS
 #define HUF_FIX_ROUNDS 4
 #endif
+#ifdef HUF_STAMPS
+} // namespace ph
+extern "C" int press_hip_huf_stamps(unsigned long long *dst, uint32_t nwords)
+{
+	unsigned long long z[32] = { 0 };
+	if (hipDeviceSynchronize() != hipSuccess ||
+	    hipMemcpyFromSymbol(dst, HIP_SYMBOL(ph::g_hstamp), (nwords < 32 ? nwords : 32) * 8) != hipSuccess ||
+	    hipMemcpyToSymbol(HIP_SYMBOL(ph::g_hstamp), z, sizeof z) != hipSuccess)
+		return -1;
+	return 0;
+}
+namespace ph {
+#endif
+
 constexpr int HUF_FIX_LAUNCHES = HUF_FIX_ROUNDS; // rounds of k_huf_fix (an ordinary table is through after two)
 
-template <int RU>
+template <int RU, bool TRIE>
 static void run_huff_decode(const DecodeArgs &a, hipStream_t s)
 {
 	// persistent workgroups: what is resident (sync: 2 per CU of four tiles each, emit: 2 of eight waves)
@@ -1282,25 +1409,37 @@ static void run_huff_decode(const DecodeArgs &a, hipStream_t s)
 	const uint32_t grid = ngs < HUF_SYNC_PER_CU * 256u ? ngs : HUF_SYNC_PER_CU * 256u;
 	const uint32_t nge = (nt * (HT / 64) + WGE / 64 - 1) / (WGE / 64);
 	const uint32_t ge = nge < EMIT_PER_CU * 256u ? nge : EMIT_PER_CU * 256u;
-	hipLaunchKernelGGL((k_huf_sync<RU>), dim3(grid), dim3(WGS), 0, s, a);
+	hipLaunchKernelGGL((k_huf_sync<RU, TRIE>), dim3(grid), dim3(WGS), 0, s, a);
 	for (int round = 0; round < HUF_FIX_LAUNCHES; round++)
-		hipLaunchKernelGGL((k_huf_fix<RU>), dim3(FIX_WG >= 1024 ? 512 : FIX_WG >= 512 ? 768 : 1280), dim3(FIX_WG), 0, s, a, round, round + 1 == HUF_FIX_LAUNCHES ? 1 : 0);
-	hipLaunchKernelGGL((k_huf_serial<RU>), dim3(a.nreads), dim3(64), 0, s, a);
+		hipLaunchKernelGGL((k_huf_fix<RU, TRIE>), dim3(FIX_WG >= 1024 ? 512 : FIX_WG >= 512 ? 768 : 1280), dim3(FIX_WG), 0, s, a, round, round + 1 == HUF_FIX_LAUNCHES ? 1 : 0);
+	hipLaunchKernelGGL((k_huf_serial<RU, TRIE>), dim3(a.nreads), dim3(64), 0, s, a);
 	hipLaunchKernelGGL(k_huf_chain, dim3(a.nreads), dim3(HT), 0, s, a);
-	hipLaunchKernelGGL((k_huf_emit<RU>), dim3(ge), dim3(WGE), 0, s, a); // (ctl->units: zero since the control block was cleared)
+	hipLaunchKernelGGL((k_huf_emit<RU, TRIE>), dim3(ge), dim3(WGE), 0, s, a); // (ctl->units: zero since the control block was cleared)
 }
 
-// Huffman stage of the exception-split decoders: payload of every read -> a.low
+template <int RU>
+static void run_huff_decode_t(const DecodeArgs &a, bool trie, hipStream_t s)
+{
+	if (trie)
+		run_huff_decode<RU, true>(a, s);
+	else
+		run_huff_decode<RU, false>(a, s);
+}
+
+// Huffman stage of the exception-split decoders: payload of every read -> a.low.  minlen: the table's shortest code
+// (selects the subsequence size) | HUF_NEEDS_TRIE if some code is beyond the second-level tables
 void launch_huff_decode(const DecodeArgs &a, uint32_t minlen, hipStream_t s)
 {
+	const bool trie = (minlen & HUF_NEEDS_TRIE) != 0;
+	minlen &= ~HUF_NEEDS_TRIE;
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
 	hipLaunchKernelGGL(k_huff_tiles, dim3((a.nreads + TILES_RPW - 1) / TILES_RPW), dim3(64), 0, s, a);
 	if (minlen >= 4)
-		run_huff_decode<128>(a, s);
+		run_huff_decode_t<128>(a, trie, s);
 	else if (minlen >= 2)
-		run_huff_decode<64>(a, s);
+		run_huff_decode_t<64>(a, trie, s);
 	else
-		run_huff_decode<32>(a, s);
+		run_huff_decode_t<32>(a, trie, s);
 }
 
 } // namespace ph

@@ -60,7 +60,17 @@ struct HuffDev {
 	// l2ld[l2off + the next l2bits stream bits]); 0xFFFFFFFF: walk the trie
 	alignas(16) uint32_t mlut[1 << HUF_LUT_BITS];
 	alignas(16) uint16_t l2ld[HUF_L2_ENTRIES]; // bits of the code | delta << 8 (signed), 0xFFFF: no such code
+	// the same first level laid out as an INCREMENT of the scan's one accumulator (position | codes << 9 |
+	// delta sum << 16): total bits | codes << HUF_A_CNT | (dsum & 0x7FFF) << HUF_A_SUM - one add per look-up moves
+	// position, count and sum (a scan covers at most 64 codes: 7 bits of count, 15 bits of signed sum).  Long
+	// codes / no code: as in mlut (the sign bit)
+	alignas(16) uint32_t alut[1 << HUF_LUT_BITS];
+	// ... and the first code alone, for the last steps in front of a limit: its bits | its delta << 8; 0: none
+	alignas(16) uint16_t flut[1 << HUF_LUT_BITS];
 };
+constexpr uint32_t HUF_A_CNT = 9, HUF_A_SUM = 16;
+constexpr uint32_t HUF_NEEDS_TRIE = 0x80000000u; // in DecodeArgs::huf_minlen: some code is beyond the second-level tables
+constexpr uint32_t HUF_L2_NONE = HUF_L2_ENTRIES - 1; // second-level slot that says "no code" (tables that need no trie)
 constexpr uint32_t HUF_MLONG = 1u << 31; // (the sign bit: one compare)
 constexpr uint32_t HUF_M_MAXN = 8; // 8 deltas of -128 .. 127 fit the 11-bit sum
 constexpr uint32_t HUF_LONG = 1u << 30;
