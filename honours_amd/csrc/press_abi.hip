@@ -91,7 +91,7 @@ struct Ctx {
 	hipStream_t user = nullptr;
 	bool use_user = false;
 	// scratch shared by both modes
-	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, htrec, hrec, hlist, hread, hwave, hend, hmin, cbits;
+	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, htrec, hrec, hlist, hread, hwave, hbits, hend, hmin, cbits;
 	DevBuf ztmp, zoff, zoff4, zlen, zhist, ztab, zfirst, zblk, zsbits, zbpos, zbflag, zkcnt, zkbase, zrd, znb, zn, zdcopy, zdhuf, zdunit, zdtree, zdctl, zdseq, zdxblk; // zstd frames
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn, dense, dense_off;
@@ -524,7 +524,8 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 			if (g.low.reserve(total_samples + 64) || g.htiles.reserve(mt * sizeof(HufTile)) ||
 			    g.htrec.reserve(mt * sizeof(HufTRec)) || g.hrec.reserve(mt * HUF_HT * 4) ||
 			    g.hlist.reserve(hlist_cap_of(mt) * 8) || g.hread.reserve(((size_t) nreads + 1) * 8) ||
-			    g.hwave.reserve(mt * (HUF_HT / 64) * 8) || g.hend.reserve(mt * HUF_HT + 64) ||
+			    g.hwave.reserve(mt * (HUF_HT / 64) * 8) || g.hbits.reserve(mt * (HUF_HT / 64) * 8) ||
+			    g.hend.reserve(mt * HUF_HT + 64) ||
 			    g.hmin.reserve(((size_t) nreads + 1) * 4))
 				return PRESS_HIP_EHIP;
 		}
@@ -1248,6 +1249,7 @@ extern "C" int press_hip_depress_batch(int method, const uint8_t *in, const uint
 		a.hlist = (uint32_t *) g.hlist.p;
 		a.hread = (uint32_t *) g.hread.p;
 		a.hwave = (uint2 *) g.hwave.p;
+		a.hbits = (unsigned long long *) g.hbits.p;
 		a.hend = (uint8_t *) g.hend.p;
 		a.hmin = (uint32_t *) g.hmin.p;
 		a.max_htiles = max_htiles_of(total_samples, nreads);

@@ -157,17 +157,30 @@ __device__ __forceinline__ void col_load(uint32_t *col, const uint8_t *src, int3
 #pragma unroll
 		for (int j = 0; j < NDW % 4; j++)
 			col[(NDW / 4 * 4 + j) * S] = x[j];
-	} else {
-		for (int j = 0; j < NDW; j++) { // rolled: the ends of a payload only
-			const int32_t r = rb0 + 4 * j;
+	} else if (nby > lo) {
+		// the ends of a payload: byte by byte, but every load unconditional (at an address clamped into the payload)
+		// and all of them in flight together - as conditional loads each waited for the one before it: 36 memory
+		// round trips in a row for the whole wave whenever one of its lanes held a payload's first or last bytes
+		uint8_t b[4 * NDW];
+#pragma unroll
+		for (int i = 0; i < 4 * NDW; i++) {
+			const int32_t r = rb0 + i;
+			b[i] = src[r < lo ? lo : (r >= nby ? nby - 1 : r)];
+		}
+#pragma unroll
+		for (int j = 0; j < NDW; j++) {
 			uint32_t x = 0;
-			if (r + 4 > lo && r < nby) {
-				for (int i = 0; i < 4; i++)
-					if (r + i >= lo && r + i < nby)
-						x |= (uint32_t) src[r + i] << (8 * i);
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const int32_t r = rb0 + 4 * j + i;
+				x |= (r >= lo && r < nby) ? (uint32_t) b[4 * j + i] << (8 * i) : 0u;
 			}
 			col[j * S] = x;
 		}
+	} else {
+#pragma unroll
+		for (int j = 0; j < NDW; j++)
+			col[j * S] = 0;
 	}
 }
 
@@ -329,7 +342,7 @@ __device__ __forceinline__ void wave_lds_sync()
 #define HUF_RUNUP_EIGHTHS 4
 #endif
 constexpr int WGS = 1024;
-constexpr int SYNC_S = 65; // dwords per row of a wave's image: 64 lanes and, in front, the subsequence before the first
+constexpr int SYNC_S = 64; // dwords per row of a wave's image (a lane's column in its own bank: no conflict whatever rows the lanes are at)
 
 // what k_huf_sync / k_huf_fix leave per subsequence: a.hrec = start | codes << 8 | sum of their deltas << 16,
 // a.hend = where the next subsequence's first code starts (0 .. 30, R_END: none)
@@ -339,7 +352,6 @@ __device__ __forceinline__ uint32_t pack_rec(uint32_t f, uint32_t c, uint32_t d)
 }
 
 constexpr uint32_t LIST_NONE = 0xFFFFFFFFu; // an unused list slot
-constexpr uint32_t LIST_CHUNK = 128;        // slots a wave of k_huf_sync takes from the list at a time
 constexpr uint32_t SYNC_UC = 16;            // quarter tiles a workgroup takes from the global counter at a time
 
 // append the lanes with `yes` to the list whose counter is *cnt (one atomic per wave)
@@ -379,8 +391,8 @@ __device__ __forceinline__ void load_len_tables(const HuffDev *hd, LenTabs *t, u
 // subsequence is its guess of the first code's start - and then through its own.  Lanes whose guess is not where the
 // left neighbour ended go on the list of k_huf_fix, and so does every unit's first lane, unchecked: where the
 // subsequence in front of it ended another wave knows (k_huf_fix drops the entry if the guess was right).  Nothing
-// is repaired here.  Units are drawn from a ticket (as in k_huf_emit); list slots are taken LIST_CHUNK at a time
-// per wave (an atomic per push - 400 000 on one counter - tripled this kernel's time), unused ones hold LIST_NONE.
+// is repaired here.  Units are drawn from a ticket (as in k_huf_emit); which lanes are to be looked at again leaves the
+// kernel as one 64-bit word per unit (DecodeArgs::hbits), from which k_huf_list makes k_huf_fix's list.
 template <int RU, bool TRIE>
 __global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(DecodeArgs a)
 {
@@ -412,9 +424,7 @@ __global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(Decod
 	uint32_t *img = imgs[threadIdx.x >> 6];
 	for (uint32_t i = lane; i < 2 * S; i += 64)
 		img[NDW * S + i] = 0;
-	uint32_t *col = img + 1 + lane;
-	const uint32_t *rcol = img + lane; // the left neighbour's column
-	uint32_t lpos = 0, lend = 0;       // the wave's chunk of the list: next free slot, end
+	uint32_t *col = img + lane;
 	HSTAMP_DECL;
 	for (;;) {
 		uint32_t u = 0;
@@ -448,64 +458,88 @@ __global__ __launch_bounds__(WGS, 2 * HUF_SYNC_PER_CU * 2) void k_huf_sync(Decod
 
 		wave_lds_sync(); // (the image is free: the last unit's scans are through)
 		col_load<NDW, S>(col, src, (int32_t) tid * (OWN / 8), 0, nby);
-		if (lane == 0 && !exact) // the bits in front of the unit belong to the same payload (maybe to the tile in front)
-			col_load<NDW, S>(img, src, (int32_t) tid * (OWN / 8) - (OWN / 8), tid ? 0 : -(OWN / 8), nby);
-		wave_lds_sync(); // columns (a lane's run-up reads its neighbour's)
+		wave_lds_sync();
 		HSTAMP(1); // descriptor + payload loads
-		// payload end in the coordinates of the own / the neighbour's column
+		// payload end in the coordinates of the own column
 		const uint32_t nb = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN);
-		const uint32_t nbr = clamp_nb((int64_t) nbits_t - (int64_t) tid * OWN + OWN);
 
-		// ---- run-up through the second half of the subsequence in front, then the own one
-		const bool first_known = lane == 0 && exact;
+		// ---- every lane runs through the END of its own subsequence: where that run crosses into the next
+		// subsequence is the right neighbour's guess of its first code's start.  (No lane reads another's column, and
+		// no bits in front of the unit are loaded: the unit's first lane has no guess - it starts at bit 0 and is
+		// listed unchecked as before; k_huf_fix decodes it again unless bit 0 happened to be right.  A second payload
+		// load for that one lane - a second memory round trip per unit - cost more than those repairs.)
 		uint32_t f, c0, c, dz, dv;
 		{
-			const uint32_t g = len_scan<TRIE, S>(rcol, &lds.tabs, a.huff, first_known ? HEND : (uint32_t) (OWN - RUNUP), OWN, nbr, c0, dz);
-			f = g == HEND ? HEND : g - OWN;
-			if (g == HEND && nb > 0)
-				f = 0; // the guess ran into a bit pattern that is no code: any guess will do
-			if (first_known)
-				f = 0;
+			const uint32_t g = len_scan<TRIE, S>(col, &lds.tabs, a.huff, (uint32_t) (OWN - RUNUP), OWN, nb, c0, dz);
+			const uint32_t gl = (uint32_t) __shfl_up((int) g, 1, 64); // the left neighbour's run
+			f = gl == HEND ? HEND : gl - OWN;
+			if (gl == HEND && nb > 0)
+				f = 0; // the run ended in the payload's last bits or in a bit pattern that is no code: any guess will do
+			if (lane == 0)
+				f = nb > 0 ? 0u : HEND;
 		}
 		HSTAMP(2); // run-up
 		const uint32_t e = len_scan<TRIE, S>(col, &lds.tabs, a.huff, f, OWN, nb, c, dv);
 		HSTAMP(3); // own pass
 		const uint32_t e8 = e == HEND ? R_END : e - OWN;
 		const uint32_t cw = wave_scan(c), dw = wave_scan(dv);
-		a.hrec[(uint64_t) k * HT + tid] = pack_rec(f, c, dv);
-		a.hend[(uint64_t) k * HT + tid] = (uint8_t) e8;
-		if (lane == 63) // the wave's totals (k_huf_fix adds what its repairs change)
-			a.hwave[u] = make_uint2(cw, dw & 0xFFFFu);
 		// ---- whose guess is not where the neighbour ended
 		const uint32_t f8 = f == HEND ? R_END : f;
 		const uint32_t pe8 = (uint32_t) __shfl_up((int) e8, 1, 64);
 		const bool broken = lane ? f8 != pe8 : !exact;
 		const unsigned long long bm = __ballot(broken);
-		if (bm) {
-			const uint32_t cnt = (uint32_t) __popcll(bm);
-			const uint32_t rem = lend - lpos, old_pos = lpos;
-			uint32_t nbase = 0;
-			if (cnt > rem) { // (cnt <= 64 <= LIST_CHUNK)
-				if (lane == 0)
-					nbase = atomicAdd(&a.ctl->ticket2, LIST_CHUNK);
-				nbase = uniform(nbase);
-				lpos = nbase + (cnt - rem);
-				lend = nbase + LIST_CHUNK;
-			} else {
-				lpos += cnt;
-			}
-			if (broken) {
-				const uint32_t j = (uint32_t) __popcll(bm & ((1ull << lane) - 1ull));
-				const uint32_t idx = j < rem ? old_pos + j : nbase + (j - rem);
-				if (idx < a.hlist_cap)
-					a.hlist[idx] = k * HT + tid;
-			}
+		a.hrec[(uint64_t) k * HT + tid] = pack_rec(f, c, dv);
+		a.hend[(uint64_t) k * HT + tid] = (uint8_t) e8;
+		// per unit: the wave's totals (k_huf_fix adds what its repairs change) and the lanes to be looked at again, one
+		// 64-bit word from which k_huf_list makes the dense list of k_huf_fix's first round.  (A list written here -
+		// slots taken 128 at a time per wave, a few scattered stores per unit - cost this kernel 80 us of its 600.
+		// Both stores by lane 63: a store by lane 0 at the end of the loop body was merged by the compiler with the
+		// ticket code of lane 0 at its top, across the wave-uniform read of the ticket - the loop never ended.)
+		if (lane == 63) {
+			a.hwave[u] = make_uint2(cw, dw & 0xFFFFu);
+			a.hbits[u] = bm;
 		}
 		HSTAMP(4); // records, list
 	}
 	HSTAMP_FLUSH(0);
-	for (uint32_t j = lpos + lane; j < lend && j < a.hlist_cap; j += 64) // what is left of the wave's last chunk
-		a.hlist[j] = LIST_NONE;
+}
+
+// The list of k_huf_fix's first round out of k_huf_sync's words: a thread per unit (a quarter tile), its set bits
+// -> entries tile * HT + subsequence; slots by ONE atomic per workgroup of 1024 units (ctl->ticket2 = the list's
+// length; an atomic per wave - 4800 returning atomics on one address - made this kernel 60 us long).
+constexpr int LIST_WG = 1024;
+__global__ __launch_bounds__(LIST_WG) void k_huf_list(DecodeArgs a)
+{
+	__shared__ uint32_t s_w[LIST_WG / 64];
+	__shared__ uint32_t s_base;
+	const uint32_t n = min(uniform(a.ctl->nchunks), a.max_htiles) * (HT / 64);
+	const uint32_t u = blockIdx.x * LIST_WG + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	unsigned long long bm = u < n ? a.hbits[u] : 0ull;
+	const uint32_t cnt = (uint32_t) __popcll(bm);
+	const uint32_t inc = wave_scan(cnt);
+	if (lane == 63)
+		s_w[w] = inc;
+	__syncthreads();
+	uint32_t before = 0, total = 0;
+#pragma unroll
+	for (int i = 0; i < LIST_WG / 64; i++) {
+		const uint32_t x = s_w[i];
+		if (i < (int) w)
+			before += x;
+		total += x;
+	}
+	if (threadIdx.x == 0)
+		s_base = total ? atomicAdd(&a.ctl->ticket2, total) : 0u;
+	__syncthreads();
+	uint32_t at = s_base + before + inc - cnt;
+	while (bm) {
+		const uint32_t b = (uint32_t) __builtin_ctzll(bm);
+		bm &= bm - 1;
+		if (at < a.hlist_cap)
+			a.hlist[at] = u * 64 + b; // = tile * HT + subsequence
+		at++;
+	}
 }
 
 // Subsequences whose start was guessed wrong, 64 to a wave: decoded again from where the subsequence in front
@@ -774,17 +808,14 @@ __device__ __forceinline__ void emit_codes(const uint32_t *col_, const uint32_t 
 			const uint32_t w2 = colm[__umul24(jj, 64u) + 128]; // the dword behind the window: on its way during the look-up
 			const uint32_t wnd = __builtin_amdgcn_alignbit(w1, w0, pp);
 			uint32_t e = *(lds_cu32p) (lut + (wnd & (((1u << HUF_LUT_BITS) - 1u) << 2)));
-			if (e >= HUF_LONG) { // rare (one code in 200): longer than 12 bits
+			if (e >= HUF_LONG) // rare (one code in 200): longer than 12 bits
 				e = long_entry(e, wnd >> 2);
-				if (e == 0) // (cannot happen: stop rather than spin)
-					wlim = w;
-			}
+			// (bits that are no code - they cannot come up among the codes k_huf_sync counted with the same
+			// tables - give e = 0: a zero is stored and the output moves on by one, so the loop ends anyway)
 			w[0] = (uint8_t) e;
 			w[1] = (uint8_t) (e >> 16);
 			w += 1u + ((e >> 29) & 1u);
 			pp += (e >> 8) & 0x1Fu;
-			if (e == 0) // (wlim == w: the loop is over, and so is the lane)
-				w = wlim = wend;
 			const uint32_t jn = pp >> 5; // a step crosses at most one dword
 			if (jn != jj) {
 				w0 = w1;
@@ -1087,6 +1118,9 @@ __device__ __forceinline__ void emit_samples16(const uint8_t *src, const EmitRea
 			for (int h = 0; h < 8; h++)
 				v[h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, v[h]) << qq);
 		}
+#if defined(EMIT_ABL) && EMIT_ABL == 1
+		if (R.nlow == 0x7FFFFFFFu)
+#endif
 #pragma unroll
 		for (int hh = 0; hh < 2; hh++) {
 			const uint32_t ia = i0 + 8 * hh;
@@ -1259,6 +1293,9 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 		const uint32_t key = (fused && quota && lane < R.nex) ? R.pos[lane] - lane : 0xFFFFFFFFu;
 		HSTAMP(2); // scan, read record
 		if (wsum <= EMIT_STG) {
+#if defined(EMIT_ABL) && EMIT_ABL == 3 // (timing experiments only: wrong results)
+			if (a.nreads == 0x7FFFFFFFu)
+#endif
 			emit_codes<TRIE, true>(col, lut, lut2, a.huff, p0, nmine, stg + ex);
 			wave_lds_sync();
 			HSTAMP(3); // decode
@@ -1266,6 +1303,9 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 				if (quota) {
 					const EmitPlan P = emit_plan(R, (uint32_t) obase, quota, B0, lane, key);
 					HSTAMP(4); // plan
+#if defined(EMIT_ABL) && EMIT_ABL == 2
+					if (a.nreads == 0x7FFFFFFFu)
+#endif
 					emit_samples16(stg, R, P, lane);
 					HSTAMP(5); // samples
 				}
@@ -1410,6 +1450,7 @@ static void run_huff_decode(const DecodeArgs &a, hipStream_t s)
 	const uint32_t nge = (nt * (HT / 64) + WGE / 64 - 1) / (WGE / 64);
 	const uint32_t ge = nge < EMIT_PER_CU * 256u ? nge : EMIT_PER_CU * 256u;
 	hipLaunchKernelGGL((k_huf_sync<RU, TRIE>), dim3(grid), dim3(WGS), 0, s, a);
+	hipLaunchKernelGGL(k_huf_list, dim3((nt * (HT / 64) + LIST_WG - 1) / LIST_WG), dim3(LIST_WG), 0, s, a);
 	for (int round = 0; round < HUF_FIX_LAUNCHES; round++)
 		hipLaunchKernelGGL((k_huf_fix<RU, TRIE>), dim3(FIX_WG >= 1024 ? 512 : FIX_WG >= 512 ? 768 : 1280), dim3(FIX_WG), 0, s, a, round, round + 1 == HUF_FIX_LAUNCHES ? 1 : 0);
 	hipLaunchKernelGGL((k_huf_serial<RU, TRIE>), dim3(a.nreads), dim3(64), 0, s, a);

@@ -185,6 +185,7 @@ struct DecodeArgs {
 	uint32_t *hmin;           // [nreads] first subsequence k_huf_fix's rounds left unsettled (0xFFFFFFFF: none)
 	uint32_t *hread;          // [2 * nreads] first tile, number of tiles of read r
 	uint2 *hwave;             // [max_htiles * 4] per wave of a tile: its codes, the sum of their deltas (mod 2^16 in the low half)
+	unsigned long long *hbits; // [max_htiles * 4] per wave of a tile: the lanes whose guess k_huf_sync found wrong or could not check
 	uint32_t max_htiles;
 	uint32_t hlist_cap;
 	uint32_t huf_minlen;      // shortest code of the table (selects the subsequence size on the host)

@@ -16,10 +16,10 @@ from honours_amd import press  # (after bench.py: torch initialises the GPU befo
 lib = press.load_library()
 lib.press_hip_huf_stamps.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
 assert lib.press_hip_huf_stamps(buf.ctypes.data, 32) == 0
-names = {0: "sync ticket", 1: "sync loads", 2: "sync run-up", 3: "sync own pass", 4: "sync records+list",
+names = {0: "sync ticket", 1: "sync loads", 2: "sync run-up", 3: "sync own pass", 4: "sync list", 5: "sync scans + record stores",
          8: "emit ticket", 9: "emit records+payload", 10: "emit scan", 11: "emit decode", 12: "emit plan", 13: "emit samples"}
 names[14] = "emit rest (waits behind the stores)"
-for grp in ((0, 1, 2, 3, 4), (8, 9, 10, 11, 12, 13, 14)):
+for grp in ((0, 1, 2, 3, 5, 4), (8, 9, 10, 11, 12, 13, 14)):
     tot = float(sum(int(buf[i]) for i in grp))
     for i in grp:
         print("%-22s %14d ticks  %5.1f %%" % (names[i], int(buf[i]), 100.0 * int(buf[i]) / tot))
