@@ -50,6 +50,7 @@
 
 #include "press_internal.h"
 #include "press_packed.h"
+#include <cstddef>
 #include <type_traits>
 
 namespace ph {
@@ -941,8 +942,9 @@ struct EmitPlan { // where a wave's samples lie and what they start from (wave-u
 // (mod 2^16); key = pos[lane] - lane of the read's first 64 exceptions, loaded by the caller BEFORE the wave
 // decodes its codes (the load is under way meanwhile).
 __device__ __forceinline__ EmitPlan emit_plan(const EmitRead &R, uint32_t L0, uint32_t quota, uint32_t B0, uint32_t lane,
-					      uint32_t key)
+					      uint32_t kraw, uint32_t vraw)
 {
+	const uint32_t key = kraw == 0xFFFFFFFFu ? kraw : kraw - lane; // kraw: pos[lane] of the read's first 64 exceptions
 	EmitPlan P;
 	P.L0 = L0;
 	P.L1 = L0 + quota;
@@ -967,12 +969,19 @@ __device__ __forceinline__ EmitPlan emit_plan(const EmitRead &R, uint32_t L0, ui
 	if (L0) {
 		P.base = unzz16(R.zd0) + B0;
 		if (Ea) {
-			const uint32_t pv = uniform(R.val[Ea - 1]);
+			// (a read of at most 64 exceptions - nearly every read - has them all in kraw / vraw, one per lane,
+			// asked for before the decode loop: no load here that the sample phase would have to wait for)
+			const uint32_t pv = nex <= 64 ? (uint32_t) __builtin_amdgcn_readlane((int) vraw, (int) (Ea - 1)) : uniform(R.val[Ea - 1]);
 			P.base += (pv >> 16) + unzz16(pv & 0xFFFFu);
 		}
 	}
 	// the wave's exceptions, one per lane (more than 64: searched where needed)
-	P.pe = (P.ecnt <= 64 && lane < P.ecnt) ? R.pos[Ea + lane] : 0xFFFFFFFFu;
+	if (nex <= 64) {
+		const uint32_t pl = (uint32_t) __shfl((int) kraw, (int) ((Ea + lane) & 63u), 64);
+		P.pe = lane < P.ecnt ? pl : 0xFFFFFFFFu;
+	} else {
+		P.pe = (P.ecnt <= 64 && lane < P.ecnt) ? R.pos[Ea + lane] : 0xFFFFFFFFu;
+	}
 	return P;
 }
 
@@ -1125,8 +1134,13 @@ __device__ __forceinline__ void emit_samples16(const uint8_t *src, const EmitRea
 		for (int hh = 0; hh < 2; hh++) {
 			const uint32_t ia = i0 + 8 * hh;
 			if (!ragged || (ia >= Ia && ia + 8 <= Ib)) {
-				const uint4 vv = make_uint4(v[4 * hh], v[4 * hh + 1], v[4 * hh + 2], v[4 * hh + 3]);
-				__builtin_memcpy(R.out + ia, &vv, 16);
+				typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+				const u32x4 vv = { v[4 * hh], v[4 * hh + 1], v[4 * hh + 2], v[4 * hh + 3] };
+#ifdef EMIT_NT_STORES
+				__builtin_nontemporal_store(vv, reinterpret_cast<u32x4 *>(R.out + ia)); // (written once, never read here)
+#else
+				*reinterpret_cast<u32x4 *>(R.out + ia) = vv;
+#endif
 			} else if (ia < Ib && ia + 8 > Ia) { // (the one group that straddles the wave's first or last sample)
 #pragma unroll
 				for (uint32_t h = 0; h < 8; h++)
@@ -1215,9 +1229,16 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 	uint8_t *stg = stg_all.s[wv];
 	__syncthreads(); // the tables; from here on every wave is on its own: columns and staging are private, and
 	                 // what the other waves of its tile hold in front of it comes with the tile's records
-	// persistent workgroups: the tables are loaded once
-	HSTAMP_DECL;
-	for (;;) {
+	// persistent workgroups: the tables are loaded once.
+	//
+	// The loop is a pipeline two units deep, so that no wave waits for a unit's records or payload: while unit N is
+	// decoded, the payload / per-lane record / read record of unit N + 1 are on their way into registers (their
+	// addresses come from the tile records of N + 1, asked for one unit earlier), and the ticket of unit N + 2 is
+	// drawn and its tile records asked for.  What arrives is used BETWEEN the decode loop and the sample phase of unit
+	// N - never right behind the sample phase's stores: vector-memory operations complete in order, and a wait for a
+	// load issued behind stores is a wait for the stores.  (Stamps before: records + payload 15 %, scan 8 % of a
+	// wave's time; an ablation without decode loop and sample phase left 0.33 of the kernel's 0.98 ms.)
+	auto draw = [&]() -> uint32_t { // the next unit of this wave (>= nunits: none)
 		uint32_t u = 0;
 		if (lane == 0) {
 			const uint32_t t = atomicAdd(&s_ticket, 1u);
@@ -1234,41 +1255,122 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 				u = (uint32_t) v + slot;
 			}
 		}
-		u = uniform(u);
-		if (u >= nunits)
-			break;
-		HSTAMP(0); // ticket
-		const uint32_t k = u / (HT / 64), k0 = k;
-		const uint32_t tid = (u % (HT / 64)) * 64 + lane; // the lane's subsequence of the tile
-		const bool has = true;
-		// the tile's two records in four loads issued together, then (their `read`) the read's: two memory round
-		// trips for everything the tile needs - field by field they were a dozen, each waited for
-		const uint4 *tp = reinterpret_cast<const uint4 *>(a.htiles + (has ? k : k0));
-		const uint4 *rp = reinterpret_cast<const uint4 *>(a.htrec + (has ? k : k0));
-		const uint4 t0 = tp[0], t1 = tp[1], r0 = rp[0], r1 = rp[1];
-		const uint32_t rec = has ? a.hrec[(uint64_t) k * HT + tid] : R_END;
-		const uint4 *hwp = reinterpret_cast<const uint4 *>(a.hwave + (uint64_t) k * (HT / 64));
-		const uint4 hw01 = hwp[0], hw23 = hwp[1]; // the totals {codes, deltas} of the tile's four waves
-		static_assert(sizeof(HufTile) == 32 && sizeof(HufTRec) == 32 && sizeof(ReadMeta) == 32, "records are two 16-byte loads");
-		const uint4 *mp = reinterpret_cast<const uint4 *>(a.meta + uniform(t1.z)); // HufTile::read
-		const uint4 m0 = mp[0], m1 = mp[1];
-		const uint32_t nbits_t = has ? uniform(t1.x) : 0u;                            // HufTile::nbits
-		const uint32_t want = uniform(t1.w);                                          // ::want
-		const uint8_t *src = a.in + (((uint64_t) uniform(t0.y) << 32) | uniform(t0.x)); // ::src
-		const uint64_t roff = ((uint64_t) uniform(t0.w) << 32) | uniform(t0.z);       // ::low: the read's slot - samples
-		uint8_t *low = a.low + roff;                                                  // in a.sig, one-byte values in a.low, exceptions
-		col_load<NDW>(col, src, (int32_t) tid * (OWN / 8), 0, (int32_t) ((nbits_t + 7) >> 3));
-		HSTAMP(1); // records + payload
+		return uniform(u);
+	};
+	static_assert(sizeof(HufTile) == 32 && sizeof(HufTRec) == 32 && sizeof(ReadMeta) == 32 && offsetof(HufTile, nbits) == 16 &&
+			      offsetof(HufTile, read) == 24 && offsetof(HufTRec, base) == 8 && offsetof(HufTRec, fused) == 28,
+		      "the records are read as eight dwords each");
+	// a unit's tile records (HufTile, HufTRec, the totals of the tile's four waves: 32 bytes each, wave-uniform) are
+	// loaded ONE DWORD PER LANE - lanes 0 .. 7 the HufTile, 8 .. 15 the HufTRec, 16 .. 23 the totals - into a single
+	// vector register and read out with v_readlane when they have arrived (as 16-byte loads of every lane, held in
+	// flight across a unit, they took 48 registers and the kernel no longer fit four waves per SIMD)
+	auto fetch_tile = [&](uint32_t u) -> uint32_t {
+		uint32_t v = 0;
+		if (u < nunits && lane < 24) {
+			const uint32_t k = u / (HT / 64);
+			const uint32_t *p = lane < 8 ? reinterpret_cast<const uint32_t *>(a.htiles + k)
+					  : lane < 16 ? reinterpret_cast<const uint32_t *>(a.htrec + k)
+						      : reinterpret_cast<const uint32_t *>(a.hwave + (uint64_t) k * (HT / 64));
+			v = p[lane & 7];
+		}
+		return v;
+	};
+	struct Unit { // what a unit needs of its tile (wave-uniform)
+		uint32_t u, nbits_t, read, want, fused, cb, db, base, dbase;
+		uint64_t srco, roff;
+	};
+	auto resolve = [&](uint32_t u, uint32_t tv) -> Unit {
+		auto at = [&](int i) -> uint32_t { return (uint32_t) __builtin_amdgcn_readlane((int) tv, i); };
+		Unit U;
+		U.u = u;
+		U.srco = ((uint64_t) at(1) << 32) | at(0); // HufTile::src
+		U.roff = ((uint64_t) at(3) << 32) | at(2); // ::low: the read's slot - samples in a.sig, one-byte values in
+		                                          // a.low, exceptions
+		U.nbits_t = at(4);                        // ::nbits
+		U.read = at(6);                           // ::read
+		U.want = at(7);                           // ::want
+		U.base = at(8 + 2);                       // HufTRec::base, ::dbase: codes of the read in front of the tile
+		U.dbase = at(8 + 3);                      // and the sum of their deltas
+		U.fused = at(8 + 7);                      // ::fused
+		const uint32_t wq = u % (HT / 64); // what the tile's waves in front of this one hold
+		U.cb = (wq > 0 ? at(16) : 0u) + (wq > 1 ? at(18) : 0u) + (wq > 2 ? at(20) : 0u);
+		U.db = (wq > 0 ? at(17) : 0u) + (wq > 1 ? at(19) : 0u) + (wq > 2 ? at(21) : 0u);
+		return U;
+	};
+	struct Stage2 { // a unit's per-lane loads: payload (in registers when every lane's 36 bytes lie inside it), record, read
+		uint32_t pay[NDW];
+		uint32_t rec;
+		uint4 m0, m1;
+		bool fast;
+	};
+	auto issue2 = [&](const Unit &U, Stage2 &S) {
+		const uint32_t tid = (U.u % (HT / 64)) * 64 + lane; // the lane's subsequence of the tile
+		const int32_t rb0 = (int32_t) tid * (OWN / 8), nby = (int32_t) ((U.nbits_t + 7) >> 3);
+		S.fast = !any64(rb0 + 4 * NDW > nby);
+		const uint8_t *q = a.in + U.srco + rb0;
+		if (S.fast) {
+			uint4 t[NDW / 4 ? NDW / 4 : 1];
+#pragma unroll
+			for (int j = 0; j < NDW / 4; j++)
+				__builtin_memcpy(&t[j], q + 16 * j, 16);
+#pragma unroll
+			for (int j = 0; j < NDW % 4; j++)
+				__builtin_memcpy(&S.pay[NDW / 4 * 4 + j], q + 4 * (NDW / 4 * 4 + j), 4);
+#pragma unroll
+			for (int j = 0; j < NDW / 4; j++) {
+				S.pay[4 * j + 0] = t[j].x;
+				S.pay[4 * j + 1] = t[j].y;
+				S.pay[4 * j + 2] = t[j].z;
+				S.pay[4 * j + 3] = t[j].w;
+			}
+		}
+		S.rec = a.hrec[(uint64_t) (U.u / (HT / 64)) * HT + tid];
+		const uint4 *mp = reinterpret_cast<const uint4 *>(a.meta + U.read);
+		S.m0 = mp[0];
+		S.m1 = mp[1];
+	};
+	auto land2 = [&](const Unit &U, const Stage2 &S) { // the payload into the wave's columns (which must be free)
+		wave_lds_sync();
+		if (S.fast) {
+#pragma unroll
+			for (int j = 0; j < NDW; j++)
+				col[j * 64] = S.pay[j];
+		} else { // a payload's last bytes: the careful loader (its loads are waited for here)
+			const uint32_t tid = (U.u % (HT / 64)) * 64 + lane;
+			col_load<NDW>(col, a.in + U.srco, (int32_t) tid * (OWN / 8), 0, (int32_t) ((U.nbits_t + 7) >> 3));
+		}
+		wave_lds_sync();
+	};
+	HSTAMP_DECL;
+	const uint32_t u_first = draw();
+	if (u_first >= nunits)
+		return;
+	Unit U = resolve(u_first, fetch_tile(u_first)), Un = {}, Unn = {};
+	Stage2 S, Sn = {};
+	issue2(U, S);
+	land2(U, S);
+	uint32_t u_nxt = draw();
+	if (u_nxt < nunits)
+		Un = resolve(u_nxt, fetch_tile(u_nxt));
+	for (;;) {
+		// ---- the units behind this one: the ticket of N + 2 and its tile records; the per-lane loads of N + 1
+		const uint32_t u_nn = draw();
+		const uint32_t tv_nn = fetch_tile(u_nn);
+		const bool more = u_nxt < nunits;
+		if (more)
+			issue2(Un, Sn);
+		HSTAMP(0); // tickets, loads of the next units
+		// ---- this unit
+		const uint32_t tid = (U.u % (HT / 64)) * 64 + lane; // the lane's subsequence of the tile
+		const uint32_t rec = S.rec;
+		const uint32_t want = U.want;
+		const uint64_t roff = U.roff;
+		uint8_t *low = a.low + roff;
 		const uint32_t cnt = (rec >> 8) & 0xFFu;
 		const uint32_t inc = wave_scan(cnt);
-		// HufTRec::base, ::dbase: codes of the read in front of the tile and the sum of their deltas; hwave: the same
-		// of the tile's waves in front of this one
-		const uint32_t wq = tid >> 6; // what the tile's waves in front of this one hold
-		const uint32_t cb = (wq > 0 ? uniform(hw01.x) : 0u) + (wq > 1 ? uniform(hw01.z) : 0u) + (wq > 2 ? uniform(hw23.x) : 0u);
-		const uint32_t db = (wq > 0 ? uniform(hw01.y) : 0u) + (wq > 1 ? uniform(hw01.w) : 0u) + (wq > 2 ? uniform(hw23.y) : 0u);
-		const uint64_t obase = (uint64_t) uniform(r0.z) + cb;
-		const uint32_t B0 = uniform(r0.w) + (db & 0xFFFFu);
-		const bool fused = has && uniform(r1.w) != 0; // ::fused
+		const uint64_t obase = (uint64_t) U.base + U.cb;
+		const uint32_t B0 = U.dbase + (U.db & 0xFFFFu);
+		const bool fused = U.fused != 0;
 		const uint32_t wsum = uniform((uint32_t) __shfl((int) inc, 63, 64));
 		// the wave delivers values [obase, obase + wsum) of the read, cut at `want`
 		const uint32_t quota = obase >= want ? 0u : (wsum < want - (uint32_t) obase ? wsum : want - (uint32_t) obase);
@@ -1282,26 +1384,37 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 			R.pos = a.ex_pos + roff;
 			R.val = a.ex_val + roff;
 			R.out = a.sig + roff;
-			R.nex = uniform(m0.x);  // ReadMeta::nex
-			R.zd0 = uniform(m0.z);  // ::zd0
-			R.q = uniform(m0.w);    // ::q
-			R.nlow = uniform(m1.z); // ::nlow
+			R.nex = uniform(S.m0.x);  // ReadMeta::nex
+			R.zd0 = uniform(S.m0.z);  // ::zd0
+			R.q = uniform(S.m0.w);    // ::q
+			R.nlow = uniform(S.m1.z); // ::nlow
 		}
+		(void) tid;
 		// symbols go to the wave's staging buffer in their final order; a wave that holds more codes than
 		// the buffer takes (cannot happen with 5.4-bit codes on average) stores them byte by byte instead
 		// (the read's first exceptions: asked for now, needed behind the decode loop)
-		const uint32_t key = (fused && quota && lane < R.nex) ? R.pos[lane] - lane : 0xFFFFFFFFu;
+		// (the position as loaded: any arithmetic on it here would put the wait for it - and for every load issued before
+		// it, the next unit's among them - in front of the decode loop)
+		const uint32_t kraw = (fused && quota && lane < R.nex) ? R.pos[lane] : 0xFFFFFFFFu;
+		const uint32_t vraw = (fused && quota && lane < R.nex) ? R.val[lane] : 0u; // (their values and delta prefixes)
 		HSTAMP(2); // scan, read record
 		if (wsum <= EMIT_STG) {
 #if defined(EMIT_ABL) && EMIT_ABL == 3 // (timing experiments only: wrong results)
 			if (a.nreads == 0x7FFFFFFFu)
 #endif
 			emit_codes<TRIE, true>(col, lut, lut2, a.huff, p0, nmine, stg + ex);
-			wave_lds_sync();
 			HSTAMP(3); // decode
+			// what was asked for at the top has arrived (the columns are free, and no store of this unit is in the way)
+			if (more)
+				land2(Un, Sn);
+			else
+				wave_lds_sync();
+			if (u_nn < nunits)
+				Unn = resolve(u_nn, tv_nn);
+			HSTAMP(1); // the next units' loads land
 			if (fused) {
 				if (quota) {
-					const EmitPlan P = emit_plan(R, (uint32_t) obase, quota, B0, lane, key);
+					const EmitPlan P = emit_plan(R, (uint32_t) obase, quota, B0, lane, kraw, vraw);
 					HSTAMP(4); // plan
 #if defined(EMIT_ABL) && EMIT_ABL == 2
 					if (a.nreads == 0x7FFFFFFFu)
@@ -1326,10 +1439,14 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 			wave_lds_sync(); // staging is free again
 		} else {
 			emit_codes<TRIE, false>(col, lut, lut2, a.huff, p0, nmine, dst + ex);
+			if (more)
+				land2(Un, Sn);
+			if (u_nn < nunits)
+				Unn = resolve(u_nn, tv_nn);
 			if (fused && quota) {
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the wave reads back what its lanes wrote
 				__builtin_amdgcn_wave_barrier();
-				emit_samples<true>(low, R, emit_plan(R, (uint32_t) obase, quota, B0, lane, key), lane);
+				emit_samples<true>(low, R, emit_plan(R, (uint32_t) obase, quota, B0, lane, kraw, vraw), lane);
 			} else if (!fused) {
 				for (uint32_t b = 0; b < nmine; b++) { // deltas -> one-byte values, in place
 					const uint32_t dl = dst[ex + b];
@@ -1338,6 +1455,12 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 			}
 		}
 		HSTAMP(6); // (the rest of a unit)
+		if (!more)
+			break;
+		U = Un;
+		S = Sn;
+		Un = Unn;
+		u_nxt = u_nn;
 	}
 	HSTAMP_FLUSH(8);
 }

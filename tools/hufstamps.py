@@ -17,7 +17,7 @@ lib = press.load_library()
 lib.press_hip_huf_stamps.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
 assert lib.press_hip_huf_stamps(buf.ctypes.data, 32) == 0
 names = {0: "sync ticket", 1: "sync loads", 2: "sync run-up", 3: "sync own pass", 4: "sync list", 5: "sync scans + record stores",
-         8: "emit ticket", 9: "emit records+payload", 10: "emit scan", 11: "emit decode", 12: "emit plan", 13: "emit samples"}
+         8: "emit tickets + next units asked for", 9: "emit next units land (after decode)", 10: "emit scan", 11: "emit decode", 12: "emit plan", 13: "emit samples"}
 names[14] = "emit rest (waits behind the stores)"
 for grp in ((0, 1, 2, 3, 5, 4), (8, 9, 10, 11, 12, 13, 14)):
     tot = float(sum(int(buf[i]) for i in grp))
