@@ -69,7 +69,7 @@ def main():
     alg = bench["roofline"]["algorithmic_bytes_per_call"]
     out = {
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python3 bench.py "
-                  "--method %s --steps 2 --warmup 1 --no-cpu --no-sub, MI355X, round 2 (tools/traffic.py); per-launch "
+                  "--method %s --steps 2 --warmup 1 --no-cpu --no-sub, MI355X (tools/traffic.py); per-launch "
                   "averages, summed over the kernels of a call" % method,
         "workload": {"method": method, "reads_per_gpu": bench["config"]["reads_per_gpu"], "seed": 20261004,
                      "fixed_len": None},
@@ -78,7 +78,7 @@ def main():
         "algorithmic_bytes_per_call": alg,
         "traffic_over_algorithmic": {"press": round(tot["press"] / alg, 3), "depress": round(tot["depress"] / alg, 3)},
     }
-    p = os.path.join(ROOT, "gpurun_out", "r02_%s_traffic.json" % method)
+    p = os.path.join(ROOT, "gpurun_out", "%s_%s_traffic.json" % (os.environ.get("ROUND_TAG", "r03"), method))
     json.dump(out, open(p, "w"), indent=1)
     print(json.dumps({"method": method, "traffic": out["traffic_bytes_per_launch"], "alg": alg,
                       "ratio": out["traffic_over_algorithmic"]}))
