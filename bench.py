@@ -362,6 +362,7 @@ def main():
                 line["configs"][key] = rec
             line["e2e_host"] = e2e_host(torch, press, b, m)
             line["per_read_api"] = per_read_api(press, b, m)
+            line["e2e_blow5"] = e2e_blow5(torch, press, b, m)
             del b
             torch.cuda.empty_cache()
             b5 = Batch(torch, press, synth, args.seed, 0, CONFIG5_READS, dev, CONFIG5_LEN)
@@ -489,6 +490,125 @@ def per_read_api(press, b, m, nreads=256):
             "press_MBps": round(raw / tp / 1e6, 1), "depress_MBps": round(raw / td / 1e6, 1),
             "value": round(raw / (tp + td) / 1e6, 1),
             "press_us_per_call": round(tp / k * 1e6, 1), "depress_us_per_call": round(td / k * 1e6, 1)}
+
+
+def e2e_blow5(torch, press, b, m, nreads=2048, batch_reads=512):
+    """The pipeline the reference's SLOW5/BLOW5 read iterator feeds, file to compressed streams on the
+    host: a BLOW5 file (zlib records, svb-zd signals: what slow5tools writes) -> press_hip_blow5_next (records
+    inflated by a pool of host threads, signal fields AS STORED into page-locked memory) -> device -> svb-zd decode
+    -> `m` -> streams back on the host.  The file holds the first `nreads` reads of the batch (made here, untimed,
+    with the library's own writer).  PCIe and file reading included: never `value`."""
+    import queue
+    import threading
+
+    like = os.path.join(ROOT, "tests", "golden", "three-reads.blow5")
+    if not os.path.exists(like):
+        return None
+    k = min(nreads, b.R)
+    n = b.n[:k]
+    # ---- the file (untimed): the device's svb-zd streams of the reads, framed and deflated by the writer
+    d_off, d_n = b.d_off[:k].contiguous(), b.d_n[:k].contiguous()
+    caps = (np.array([press.bound("slow5_svb_zd", int(x)) for x in n], dtype=np.int64) + 64 + 127) // 128 * 128
+    out_off = np.concatenate([[0], np.cumsum(caps)])
+    d_tmp = torch.empty(int(out_off[-1]) + 64, dtype=torch.uint8, device=b.dev)
+    d_len = torch.zeros(k, dtype=torch.int64, device=b.dev)
+    press.press_batch("slow5_svb_zd", b.sig, d_off, d_n, d_tmp, torch.from_numpy(out_off).to(b.dev), d_len)
+    torch.cuda.synchronize()
+    host, lens = d_tmp.cpu().numpy(), d_len.cpu().numpy()
+    fields = [host[int(out_off[r]): int(out_off[r]) + int(lens[r])] for r in range(k)]
+    path = "/tmp/press_hip_bench_%d.blow5" % os.getpid()
+    press.blow5_write_like(path, like, fields, record_method=1, signal_method=1)
+    del d_tmp, host, fields
+    file_bytes = os.path.getsize(path)
+    raw = 2 * int(n.sum())
+    if m.startswith("shuffman"):
+        press.load_table()
+    arena_cap = 1 << 30
+    try:
+        # ---- the reader alone (file -> inflated signal fields in page-locked memory)
+        pin = [torch.empty(arena_cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        meta = [(np.zeros(batch_reads, np.uint64), np.zeros(batch_reads, np.uint64), np.zeros(batch_reads, np.uint32))
+                for _ in range(2)]
+
+        def reader_pass(consume):
+            rd = press.Blow5Reader(path)
+            q = queue.Queue(maxsize=1)
+
+            def produce():
+                slot = 0
+                while True:
+                    off, ln, ns = meta[slot]
+                    got = rd.next_arena(pin[slot].numpy(), off, ln, ns, batch_reads)
+                    q.put((slot, got))
+                    if got == 0:
+                        return
+                    slot ^= 1
+
+            th = threading.Thread(target=produce)
+            th.start()
+            reads = 0
+            while True:
+                slot, got = q.get()
+                if got == 0:
+                    break
+                consume(slot, got)
+                reads += got
+            th.join()
+            rd.close()
+            return reads
+
+        t0 = time.perf_counter()
+        assert reader_pass(lambda slot, got: None) == k
+        t_reader = time.perf_counter() - t0
+
+        # ---- the whole way
+        total_comp = [0]
+        check = []
+
+        def gpu_batch(slot, got):
+            off, ln, ns = meta[slot]
+            used = int(off[got - 1] + ln[got - 1])
+            d_in = pin[slot][:used + 64].to(b.dev, non_blocking=True)
+            nsv = ns[:got].astype(np.int64)
+            starts = np.concatenate([[0], np.cumsum((nsv + 63) // 64 * 64)])
+            d_in_off = torch.from_numpy(off[:got].astype(np.int64)).to(b.dev)
+            d_in_len = torch.from_numpy(ln[:got].astype(np.int64)).to(b.dev)
+            d_soff = torch.from_numpy(starts[:-1].copy()).to(b.dev)
+            d_ns = torch.from_numpy(nsv.astype(np.int32)).to(b.dev)
+            d_sig = torch.empty(int(starts[-1]) + 64, dtype=torch.int16, device=b.dev)
+            d_outn = torch.zeros(got, dtype=torch.int32, device=b.dev)
+            press.depress_batch("slow5_svb_zd", d_in, d_in_off, d_in_len, d_sig, d_soff, d_ns, d_outn)
+            cp = (np.array([press.bound(m, int(x)) for x in nsv], dtype=np.int64) + 64 + 127) // 128 * 128
+            oo = np.concatenate([[0], np.cumsum(cp)])
+            d_out = torch.empty(int(oo[-1]) + 64, dtype=torch.uint8, device=b.dev)
+            d_l = torch.zeros(got, dtype=torch.int64, device=b.dev)
+            press.press_batch(m, d_sig, d_soff, d_ns, d_out, torch.from_numpy(oo).to(b.dev), d_l)
+            h_out = d_out.cpu()  # (the streams cross the link in their slots; lengths beside them)
+            h_len = d_l.cpu().numpy()
+            assert (h_len > 0).all() and bool((d_outn.cpu().numpy() == nsv).all())
+            total_comp[0] += int(h_len.sum())
+            if not check:  # the first batch against the batch's own samples
+                first = d_sig[: int(nsv[0])].cpu()
+                check.append(bool(torch.equal(first, b.sig[int(b.starts[0]): int(b.starts[0]) + int(nsv[0])].cpu())))
+            del h_out
+
+        reader_pass(gpu_batch)  # warm-up (scratch, allocator)
+        total_comp[0] = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        assert reader_pass(gpu_batch) == k
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        assert check and check[0], "BLOW5 e2e: the decoded samples differ"
+    finally:
+        os.remove(path)
+    return {"what": "BLOW5 file (zlib records, svb-zd signals) -> press_hip_blow5_next on a pool of host threads -> "
+                    "page-locked arena -> device: slow5_svb_zd decode -> %s -> streams on the host; %d reads per batch, "
+                    "the reader one batch ahead of the device" % (m, batch_reads),
+            "reads": k, "raw_bytes": raw, "file_bytes": file_bytes, "compressed_bytes": total_comp[0],
+            "ratio_vs_file": round(file_bytes / total_comp[0], 4), "unit": "MB/s",
+            "value": round(raw / t_all / 1e6, 1), "reader_alone_MBps": round(raw / t_reader / 1e6, 1),
+            "file_MBps": round(file_bytes / t_all / 1e6, 1), "host_threads": min(os.cpu_count() or 1, 32)}
 
 
 def libzstd_frames(torch, press, b, steps, nreads=1024):

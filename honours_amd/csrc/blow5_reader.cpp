@@ -26,7 +26,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <deque>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/press_hip.h"
@@ -91,70 +94,149 @@ struct press_hip_blow5 {
 	uint32_t num_read_groups = 0;
 	std::string header;
 	uint8_t fixed[68];              // the 64-byte binary header + the text header's size
-	std::vector<uint8_t> comp, rec; // one record: as stored, inflated
-	bool have_pending = false;      // `rec` holds a record that did not fit the last batch
+	std::vector<uint8_t> rec;       // the record at the head of the queue (inflated)
+	bool have_pending = false;      // `rec` holds a record that has not been handed out yet
 	bool at_eof = false;
+	// records are read from the file in blocks and inflated by a pool of host threads (zlib's inflate of one record
+	// after the other on one thread fed the device at ~0.3 GB/s): what is inflated waits here in file order
+	std::deque<std::vector<uint8_t>> ready;
+	int threads = 0;                // 0: as many as the host offers, at most 32
 };
 
 namespace {
 
-// reads the next record into f->rec (inflated); 0 ok, 1 end of file, < 0 error
-int next_record(press_hip_blow5 *f)
+// inflate one record as stored (`comp`) into `rec`; 0 ok, < 0 error (message in *err)
+int inflate_record(int record_method, std::vector<uint8_t> &comp, std::vector<uint8_t> &rec, const char **err)
 {
-	uint8_t sz[8];
-	const size_t got = fread(sz, 1, 8, f->fp);
-	if (got >= 5 && !memcmp(sz, "5WOLB", 5)) {
-		f->at_eof = true;
-		return 1;
-	}
-	if (got == 0 && feof(f->fp)) { // a file without the end marker: tolerated like a truncated tail is not
-		f->at_eof = true;
-		return 1;
-	}
-	if (got != 8)
-		return b5_fail(PRESS_HIP_EARG, "BLOW5: truncated record size");
-	uint64_t n;
-	memcpy(&n, sz, 8);
-	if (n == 0 || n > (1ull << 34))
-		return b5_fail(PRESS_HIP_EARG, "BLOW5: implausible record size");
-	f->comp.resize(n);
-	if (fread(f->comp.data(), 1, n, f->fp) != n)
-		return b5_fail(PRESS_HIP_EARG, "BLOW5: truncated record");
-	if (f->record_method == 0) {
-		f->rec.swap(f->comp);
+	const size_t n = comp.size();
+	if (record_method == 0) {
+		rec.swap(comp);
 		return 0;
 	}
-	inf.open();
-	if (f->record_method == 1) { // zlib (slow5_press.c ptr_depress_zlib): the inflated size is not stored
-		if (!inf.z_uncompress)
-			return b5_fail(PRESS_HIP_EARG, "BLOW5: zlib record compression but libz is not available");
+	if (record_method == 1) { // zlib (slow5_press.c ptr_depress_zlib): the inflated size is not stored
 		size_t cap = n * 4 + 4096;
 		for (;;) {
-			f->rec.resize(cap);
+			rec.resize(cap);
 			unsigned long out = (unsigned long) cap;
-			const int rc = inf.z_uncompress(f->rec.data(), &out, f->comp.data(), (unsigned long) n);
+			const int rc = inf.z_uncompress(rec.data(), &out, comp.data(), (unsigned long) n);
 			if (rc == 0) {
-				f->rec.resize(out);
+				rec.resize(out);
 				return 0;
 			}
-			if (rc != -5 /* Z_BUF_ERROR */ || cap > (1ull << 34))
-				return b5_fail(PRESS_HIP_EARG, "BLOW5: zlib could not inflate a record");
+			if (rc != -5 /* Z_BUF_ERROR */ || cap > (1ull << 34)) {
+				*err = "BLOW5: zlib could not inflate a record";
+				return PRESS_HIP_EARG;
+			}
 			cap *= 2;
 		}
 	}
-	if (f->record_method == 2) { // zstd
-		if (!inf.zs_decompress || !inf.zs_content_size || !inf.zs_is_error)
-			return b5_fail(PRESS_HIP_EARG, "BLOW5: zstd record compression but libzstd is not available");
-		const unsigned long long want = inf.zs_content_size(f->comp.data(), n);
-		if (want == 0ULL - 1 || want == 0ULL - 2 || want > (1ull << 34))
-			return b5_fail(PRESS_HIP_EARG, "BLOW5: zstd frame without a usable content size");
-		f->rec.resize((size_t) want);
-		const size_t out = inf.zs_decompress(f->rec.data(), (size_t) want, f->comp.data(), n);
-		if (inf.zs_is_error(out) || out != want)
-			return b5_fail(PRESS_HIP_EARG, "BLOW5: zstd could not inflate a record");
-		return 0;
+	// zstd
+	const unsigned long long want = inf.zs_content_size(comp.data(), n);
+	if (want == 0ULL - 1 || want == 0ULL - 2 || want > (1ull << 34)) {
+		*err = "BLOW5: zstd frame without a usable content size";
+		return PRESS_HIP_EARG;
 	}
-	return b5_fail(PRESS_HIP_EARG, "BLOW5: unknown record compression method");
+	rec.resize((size_t) want);
+	const size_t out = inf.zs_decompress(rec.data(), (size_t) want, comp.data(), n);
+	if (inf.zs_is_error(out) || out != want) {
+		*err = "BLOW5: zstd could not inflate a record";
+		return PRESS_HIP_EARG;
+	}
+	return 0;
+}
+
+unsigned pool_size(int asked, size_t jobs)
+{
+	unsigned t = asked > 0 ? (unsigned) asked : std::thread::hardware_concurrency();
+	if (t == 0)
+		t = 1;
+	if (t > 32)
+		t = 32;
+	if (t > jobs)
+		t = (unsigned) jobs;
+	return t ? t : 1;
+}
+
+// Reads the next block of records from the file (up to `want` records or ~64 MiB as stored) and inflates them on the
+// pool, into f->ready in file order.  0 ok (f->ready may stay empty at the end of the file), < 0 error.
+int fill_ready(press_hip_blow5 *f, uint32_t want)
+{
+	std::vector<std::vector<uint8_t>> comp;
+	uint64_t bytes = 0;
+	while (!f->at_eof && comp.size() < want && bytes < (64ull << 20)) {
+		uint8_t sz[8];
+		const size_t got = fread(sz, 1, 8, f->fp);
+		if (got >= 5 && !memcmp(sz, "5WOLB", 5)) {
+			f->at_eof = true;
+			break;
+		}
+		if (got == 0 && feof(f->fp)) { // a file without the end marker: tolerated like a truncated tail is not
+			f->at_eof = true;
+			break;
+		}
+		if (got != 8)
+			return b5_fail(PRESS_HIP_EARG, "BLOW5: truncated record size");
+		uint64_t n;
+		memcpy(&n, sz, 8);
+		if (n == 0 || n > (1ull << 34))
+			return b5_fail(PRESS_HIP_EARG, "BLOW5: implausible record size");
+		comp.emplace_back(n);
+		if (fread(comp.back().data(), 1, n, f->fp) != n)
+			return b5_fail(PRESS_HIP_EARG, "BLOW5: truncated record");
+		bytes += n;
+	}
+	if (comp.empty())
+		return 0;
+	if (f->record_method) {
+		inf.open();
+		if (f->record_method == 1 && !inf.z_uncompress)
+			return b5_fail(PRESS_HIP_EARG, "BLOW5: zlib record compression but libz is not available");
+		if (f->record_method == 2 && (!inf.zs_decompress || !inf.zs_content_size || !inf.zs_is_error))
+			return b5_fail(PRESS_HIP_EARG, "BLOW5: zstd record compression but libzstd is not available");
+		if (f->record_method > 2)
+			return b5_fail(PRESS_HIP_EARG, "BLOW5: unknown record compression method");
+	}
+	std::vector<std::vector<uint8_t>> out(comp.size());
+	std::atomic<size_t> next(0);
+	std::atomic<int> bad(0);
+	const char *first_err = nullptr;
+	auto work = [&]() {
+		for (;;) {
+			const size_t i = next.fetch_add(1);
+			if (i >= comp.size())
+				break;
+			const char *e = nullptr;
+			if (inflate_record(f->record_method, comp[i], out[i], &e) && !bad.exchange(1))
+				first_err = e;
+		}
+	};
+	const unsigned nt = f->record_method ? pool_size(f->threads, comp.size()) : 1;
+	std::vector<std::thread> pool;
+	for (unsigned t = 1; t < nt; t++)
+		pool.emplace_back(work);
+	work();
+	for (auto &t : pool)
+		t.join();
+	if (bad.load())
+		return b5_fail(PRESS_HIP_EARG, first_err ? first_err : "BLOW5: a record does not inflate");
+	for (auto &r : out)
+		f->ready.emplace_back(std::move(r));
+	return 0;
+}
+
+// the next record into f->rec (inflated); 0 ok, 1 end of file, < 0 error.  `ahead`: records the caller may still take
+int next_record(press_hip_blow5 *f, uint32_t ahead = 1)
+{
+	if (f->ready.empty()) {
+		const int rc = fill_ready(f, ahead < 16 ? 16 : ahead);
+		if (rc)
+			return rc;
+		if (f->ready.empty())
+			return 1;
+	}
+	f->rec.swap(f->ready.front());
+	f->ready.pop_front();
+	return 0;
 }
 
 struct RecView {
@@ -252,6 +334,14 @@ void press_hip_blow5_close(press_hip_blow5 *f)
 	delete f;
 }
 
+int press_hip_blow5_threads(press_hip_blow5 *f, int threads)
+{
+	if (!f || threads < 0)
+		return b5_fail(PRESS_HIP_EARG, "BLOW5: bad argument");
+	f->threads = threads;
+	return 0;
+}
+
 int press_hip_blow5_methods(const press_hip_blow5 *f, int *record_method, int *signal_method)
 {
 	if (!f)
@@ -272,9 +362,9 @@ int press_hip_blow5_next(press_hip_blow5 *f, uint32_t max_reads, uint8_t *arena,
 	uint64_t used = 0;
 	while (k < max_reads) {
 		if (!f->have_pending) {
-			if (f->at_eof)
+			if (f->at_eof && f->ready.empty())
 				break;
-			const int rc = next_record(f);
+			const int rc = next_record(f, max_reads - k);
 			if (rc == 1)
 				break;
 			if (rc)
@@ -323,9 +413,9 @@ int press_hip_blow5_next_records(press_hip_blow5 *f, uint32_t max_reads, uint8_t
 	uint64_t used = 0;
 	while (k < max_reads) {
 		if (!f->have_pending) {
-			if (f->at_eof)
+			if (f->at_eof && f->ready.empty())
 				break;
-			const int rc = next_record(f);
+			const int rc = next_record(f, max_reads - k);
 			if (rc == 1)
 				break;
 			if (rc)
@@ -360,6 +450,18 @@ struct press_hip_blow5_writer {
 	FILE *fp = nullptr;
 	int record_method = 0, signal_method = 0;
 	std::vector<uint8_t> rec, comp;
+	// the index slow5lib keeps beside a BLOW5 file (slow5_idx.c:269 slow5_idx_write): read id -> offset and size of
+	// its record (the size field included); written by press_hip_blow5_finish when asked for
+	bool want_index = false;
+	std::string path;
+	uint8_t version[3] = { 0, 2, 0 };
+	uint64_t at = 0; // file offset of the next record
+	struct Entry {
+		std::string id;
+		uint64_t offset, size;
+	};
+	std::vector<Entry> index;
+	int threads = 0;
 };
 
 int press_hip_blow5_create(const char *path, const press_hip_blow5 *like, int record_method, int signal_method,
@@ -395,9 +497,68 @@ int press_hip_blow5_create(const char *path, const press_hip_blow5 *like, int re
 	w->fp = fp;
 	w->record_method = record_method;
 	w->signal_method = signal_method;
+	w->path = path;
+	memcpy(w->version, h + 6, 3);
+	w->at = sizeof h + like->header.size();
 	*out = w;
 	return 0;
 }
+
+// Keep an index while writing and leave it as <path>.idx when the file is finished: slow5lib's slow5_idx_load /
+// slow5_get then find a read of the transcoded file by its id without scanning it (slow5_idx.c).
+int press_hip_blow5_index(press_hip_blow5_writer *w, int enable)
+{
+	if (!w)
+		return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: NULL handle");
+	w->want_index = enable != 0;
+	return 0;
+}
+
+namespace {
+
+// frame one record (pre | u64 length | sig | post) and, for zlib files, deflate it: -> body
+int frame_record(int record_method, int signal_method, const uint8_t *pre, uint64_t pre_len, const uint8_t *sig, uint64_t sig_len,
+		 const uint8_t *post, uint64_t post_len, std::vector<uint8_t> &rec, std::vector<uint8_t> &body)
+{
+	const uint64_t lenfield = signal_method ? sig_len : sig_len / 2; // slow5.c:3960
+	rec.resize(pre_len + 8 + sig_len + post_len);
+	memcpy(rec.data(), pre, pre_len);
+	memcpy(rec.data() + pre_len, &lenfield, 8);
+	if (sig_len)
+		memcpy(rec.data() + pre_len + 8, sig, sig_len);
+	if (post_len)
+		memcpy(rec.data() + pre_len + 8 + sig_len, post, post_len);
+	if (record_method == 1) {
+		unsigned long cap = inf.z_bound((unsigned long) rec.size());
+		body.resize(cap);
+		if (inf.z_compress2(body.data(), &cap, rec.data(), (unsigned long) rec.size(), -1 /* Z_DEFAULT_COMPRESSION */))
+			return -1;
+		body.resize(cap);
+	} else {
+		body.swap(rec);
+	}
+	return 0;
+}
+
+int put_record(press_hip_blow5_writer *w, const uint8_t *pre, uint64_t pre_len, const std::vector<uint8_t> &body)
+{
+	const uint64_t n = body.size();
+	if (fwrite(&n, 8, 1, w->fp) != 1 || fwrite(body.data(), 1, n, w->fp) != n)
+		return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: write failed");
+	if (w->want_index) {
+		uint16_t idl = 0;
+		if (pre_len >= 2)
+			memcpy(&idl, pre, 2);
+		if ((uint64_t) idl + 2 > pre_len)
+			return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: the record's read id runs past its front part");
+		w->index.push_back({ std::string((const char *) pre + 2, idl), w->at, 8 + n });
+	}
+	w->at += 8 + n;
+	return 0;
+}
+
+} // namespace
+
 
 // One record: `pre` = everything in front of the signal's length field (read id ... sampling
 // rate), `sig` = the signal field in the writer's signal method, `post` = the auxiliary fields.
@@ -406,26 +567,47 @@ int press_hip_blow5_write(press_hip_blow5_writer *w, const uint8_t *pre, uint64_
 {
 	if (!w || !pre || (!sig && sig_len) || (!post && post_len))
 		return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: NULL argument");
-	const uint64_t lenfield = w->signal_method ? sig_len : sig_len / 2; // slow5.c:3960
-	w->rec.resize(pre_len + 8 + sig_len + post_len);
-	memcpy(w->rec.data(), pre, pre_len);
-	memcpy(w->rec.data() + pre_len, &lenfield, 8);
-	if (sig_len)
-		memcpy(w->rec.data() + pre_len + 8, sig, sig_len);
-	if (post_len)
-		memcpy(w->rec.data() + pre_len + 8 + sig_len, post, post_len);
-	const uint8_t *body = w->rec.data();
-	uint64_t n = w->rec.size();
-	if (w->record_method == 1) {
-		unsigned long cap = inf.z_bound((unsigned long) n);
-		w->comp.resize(cap);
-		if (inf.z_compress2(w->comp.data(), &cap, body, (unsigned long) n, -1 /* Z_DEFAULT_COMPRESSION */))
-			return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: zlib failed");
-		body = w->comp.data();
-		n = cap;
+	if (frame_record(w->record_method, w->signal_method, pre, pre_len, sig, sig_len, post, post_len, w->rec, w->comp))
+		return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: zlib failed");
+	return put_record(w, pre, pre_len, w->comp);
+}
+
+// n records at once: framed and deflated by a pool of host threads (zlib's deflate is the slow part of writing a
+// BLOW5: ~30 MB/s on one thread), written in the order given.
+int press_hip_blow5_write_batch(press_hip_blow5_writer *w, uint32_t n, const uint8_t *const *pre, const uint64_t *pre_len,
+				const uint8_t *const *sig, const uint64_t *sig_len, const uint8_t *const *post,
+				const uint64_t *post_len)
+{
+	if (!w || (n && (!pre || !pre_len || !sig || !sig_len || !post_len)))
+		return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: NULL argument");
+	std::vector<std::vector<uint8_t>> body(n);
+	std::atomic<uint32_t> next(0);
+	std::atomic<int> bad(0);
+	auto work = [&]() {
+		std::vector<uint8_t> rec;
+		for (;;) {
+			const uint32_t i = next.fetch_add(1);
+			if (i >= n)
+				break;
+			if (frame_record(w->record_method, w->signal_method, pre[i], pre_len[i], sig[i], sig_len[i],
+					 post ? post[i] : nullptr, post_len[i], rec, body[i]))
+				bad.store(1);
+		}
+	};
+	const unsigned nt = w->record_method ? pool_size(w->threads, n) : 1;
+	std::vector<std::thread> pool;
+	for (unsigned t = 1; t < nt; t++)
+		pool.emplace_back(work);
+	work();
+	for (auto &t : pool)
+		t.join();
+	if (bad.load())
+		return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: zlib failed");
+	for (uint32_t i = 0; i < n; i++) {
+		const int rc = put_record(w, pre[i], pre_len[i], body[i]);
+		if (rc)
+			return rc;
 	}
-	if (fwrite(&n, 8, 1, w->fp) != 1 || fwrite(body, 1, n, w->fp) != n)
-		return b5_fail(PRESS_HIP_EARG, "BLOW5 writer: write failed");
 	return 0;
 }
 
@@ -439,6 +621,24 @@ int press_hip_blow5_finish(press_hip_blow5_writer *w)
 			rc = b5_fail(PRESS_HIP_EARG, "BLOW5 writer: write failed");
 		if (fclose(w->fp))
 			rc = b5_fail(PRESS_HIP_EARG, "BLOW5 writer: close failed");
+	}
+	if (!rc && w->want_index) {
+		// slow5_idx.c:269: "SLOW5IDX\1" | the file's version | zeros up to byte 64 | per read: u16 id length, id,
+		// u64 offset, u64 size | "XDI5WOLS"
+		FILE *ip = fopen((w->path + ".idx").c_str(), "wb");
+		uint8_t head[64] = { 'S', 'L', 'O', 'W', '5', 'I', 'D', 'X', 1, w->version[0], w->version[1], w->version[2] };
+		bool ok = ip && fwrite(head, 1, sizeof head, ip) == sizeof head;
+		for (size_t i = 0; ok && i < w->index.size(); i++) {
+			const press_hip_blow5_writer::Entry &e = w->index[i];
+			const uint16_t idl = (uint16_t) e.id.size();
+			ok = fwrite(&idl, 2, 1, ip) == 1 && (idl == 0 || fwrite(e.id.data(), 1, idl, ip) == idl) &&
+			     fwrite(&e.offset, 8, 1, ip) == 1 && fwrite(&e.size, 8, 1, ip) == 1;
+		}
+		ok = ok && fwrite("XDI5WOLS", 1, 8, ip) == 8;
+		if (ip && fclose(ip))
+			ok = false;
+		if (!ok)
+			rc = b5_fail(PRESS_HIP_EARG, "BLOW5 writer: could not write the index");
 	}
 	delete w;
 	return rc;

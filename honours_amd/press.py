@@ -77,7 +77,8 @@ HEADER_SYMBOLS = sorted(set(
      "press_hip_slow5_ptr_compress_svb_zd", "press_hip_slow5_ptr_depress_svb_zd",
      "press_hip_blow5_open", "press_hip_blow5_close", "press_hip_blow5_methods", "press_hip_blow5_next",
      "press_hip_blow5_last_error", "press_hip_blow5_next_records", "press_hip_blow5_create",
-     "press_hip_blow5_write", "press_hip_blow5_finish",
+     "press_hip_blow5_write", "press_hip_blow5_finish", "press_hip_blow5_write_batch", "press_hip_blow5_index",
+     "press_hip_blow5_threads",
      "press_hip_shutdown", "press_hip_scratch_buffers", "press_hip_host_alloc", "press_hip_host_free",
      "press_hip_zstd_host_frames"]))
 
@@ -523,21 +524,115 @@ class Blow5Reader:
             out.append((rid, int(ns[k]), arena[int(off[k]):int(off[k]) + int(ln[k])].tobytes()))
         return out
 
+    def set_threads(self, n):
+        """host threads that inflate records (0: as many as the host offers, at most 32)"""
+        lib = load_library()
+        lib.press_hip_blow5_threads.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        if lib.press_hip_blow5_threads(self._h, int(n)):
+            raise PressError(lib.press_hip_blow5_last_error().decode())
+
+    def next_arena(self, arena, off, ln, ns, max_reads):
+        """the raw call: signal fields into the caller's arena (numpy uint8; page-locked memory from
+        press.host_alloc for a fast copy to the device), offsets / lengths / sample counts into off / ln / ns
+        (numpy uint64, uint64, uint32 of >= max_reads).  -> reads delivered (0 at the end of the file)"""
+        lib = load_library()
+        got = ctypes.c_uint32()
+        if lib.press_hip_blow5_next(self._h, max_reads, arena.ctypes.data, arena.size, off.ctypes.data,
+                                    ln.ctypes.data, ns.ctypes.data, None, ctypes.byref(got)):
+            raise PressError(lib.press_hip_blow5_last_error().decode())
+        return got.value
+
     def close(self):
         if self._h:
             load_library().press_hip_blow5_close(self._h)
             self._h = ctypes.c_void_p()
 
 
-def blow5_transcode(src, dst, record_method=1, signal_method=1, codec=None, passthrough=False):
+def _blow5_writer_api(lib):
+    lib.press_hip_blow5_last_error.restype = ctypes.c_char_p
+    lib.press_hip_blow5_create.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                           ctypes.POINTER(ctypes.c_void_p)]
+    lib.press_hip_blow5_write.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                          ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    lib.press_hip_blow5_write_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 6
+    lib.press_hip_blow5_index.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.press_hip_blow5_finish.argtypes = [ctypes.c_void_p]
+
+
+def _blow5_write_batch(lib, w, pres, sigs, posts):
+    """press_hip_blow5_write_batch over lists of numpy uint8 arrays (posts may hold empty arrays)"""
+    n = len(pres)
+    PT = ctypes.c_void_p * n
+    LT = ctypes.c_uint64 * n
+    pre_p, sig_p, post_p = PT(), PT(), PT()
+    pre_l, sig_l, post_l = LT(), LT(), LT()
+    for k in range(n):
+        pre_p[k], pre_l[k] = pres[k].ctypes.data, pres[k].size
+        sig_p[k], sig_l[k] = (sigs[k].ctypes.data if sigs[k].size else None), sigs[k].size
+        post_p[k], post_l[k] = (posts[k].ctypes.data if posts[k].size else None), posts[k].size
+    if lib.press_hip_blow5_write_batch(w, n, pre_p, pre_l, sig_p, sig_l, post_p, post_l):
+        raise PressError(lib.press_hip_blow5_last_error().decode())
+
+
+def blow5_write_like(dst, like, fields, record_method=1, signal_method=1, index=False, ids=None):
+    """A BLOW5 file with the header of `like` and one record per entry of `fields` (signal fields in the given
+    signal method: svb-zd streams or int16 samples as bytes); every record takes the fixed fields and auxiliary
+    fields of `like`'s first record and a read id of its own (ids, default "read-%08d" padded to the template's
+    length).  For benchmarks and tests: a file of any size with realistic framing.  -> the read ids"""
+    lib = load_library()
+    _blow5_writer_api(lib)
+    rd = Blow5Reader(like)
+    lib.press_hip_blow5_next_records.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64] + \
+        [ctypes.c_void_p] * 5 + [ctypes.POINTER(ctypes.c_uint32)]
+    cap = 1 << 26
+    arena = np.empty(cap, dtype=np.uint8)
+    ro, rl, sp, sl = (np.zeros(1, dtype=np.uint64) for _ in range(4))
+    ns = np.zeros(1, dtype=np.uint32)
+    got = ctypes.c_uint32()
+    if lib.press_hip_blow5_next_records(rd._h, 1, arena.ctypes.data, cap, ro.ctypes.data, rl.ctypes.data, sp.ctypes.data,
+                                        sl.ctypes.data, ns.ctypes.data, ctypes.byref(got)) or got.value != 1:
+        rd.close()
+        raise PressError("no template record in " + like)
+    rec = arena[int(ro[0]):int(ro[0]) + int(rl[0])].copy()
+    idl = int(rec[0]) | (int(rec[1]) << 8)
+    fixed = rec[2 + idl:int(sp[0]) - 8].copy()          # read group, digitisation ... sampling rate
+    post = rec[int(sp[0]) + int(sl[0]):].copy()         # auxiliary fields
+    w = ctypes.c_void_p()
+    if lib.press_hip_blow5_create(dst.encode(), rd._h, record_method, signal_method, ctypes.byref(w)):
+        rd.close()
+        raise PressError(lib.press_hip_blow5_last_error().decode())
+    rd.close()
+    out_ids = []
+    try:
+        if index:
+            lib.press_hip_blow5_index(w, 1)
+        B = 512
+        for k0 in range(0, len(fields), B):
+            pres, sigs, posts = [], [], []
+            for k in range(k0, min(k0 + B, len(fields))):
+                rid = (ids[k] if ids else "read-%08d" % k).encode()
+                out_ids.append(rid.decode())
+                pres.append(np.frombuffer(bytes([len(rid) & 255, len(rid) >> 8]) + rid + fixed.tobytes(), dtype=np.uint8))
+                f = fields[k]
+                sigs.append(f if isinstance(f, np.ndarray) else np.frombuffer(f, dtype=np.uint8))
+                posts.append(post)
+            _blow5_write_batch(lib, w, pres, sigs, posts)
+    finally:
+        if lib.press_hip_blow5_finish(w):
+            raise PressError(lib.press_hip_blow5_last_error().decode())
+    return out_ids
+
+
+def blow5_transcode(src, dst, record_method=1, signal_method=1, codec=None, passthrough=False, index=False):
     """BLOW5 -> BLOW5 with the signal fields re-coded: codec(list of int16 arrays) -> list of svb-zd
     streams (default: the device, press_batch_host("slow5_svb_zd")); signal_method 0 writes the raw
     samples.  Signals of the source are decoded on the device when it stores them as svb-zd.
     passthrough: keep the signal fields as they are (source and target signal method must agree;
     no GPU involved - only the record framing / record compression changes).
+    index: also write slow5lib's <dst>.idx (the reference's slow5_get then works on the transcoded file).
     Returns the number of reads written."""
     lib = load_library()
-    lib.press_hip_blow5_last_error.restype = ctypes.c_char_p
+    _blow5_writer_api(lib)
     rd = Blow5Reader(src)
     lib.press_hip_blow5_next_records.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64] + \
         [ctypes.c_void_p] * 5 + [ctypes.POINTER(ctypes.c_uint32)]
@@ -552,6 +647,8 @@ def blow5_transcode(src, dst, record_method=1, signal_method=1, codec=None, pass
         raise PressError(lib.press_hip_blow5_last_error().decode())
     total = 0
     try:
+        if index:
+            lib.press_hip_blow5_index(w, 1)
         maxr, cap = 1024, 1 << 28
         arena = np.empty(cap, dtype=np.uint8)
         ro, rl, sp, sl = (np.zeros(maxr, dtype=np.uint64) for _ in range(4))
@@ -582,13 +679,9 @@ def blow5_transcode(src, dst, record_method=1, signal_method=1, codec=None, pass
                 out = (codec or (lambda reads: press_batch_host("slow5_svb_zd", reads)))(sigs)
             else:
                 out = [np.ascontiguousarray(s, dtype=np.int16).tobytes() for s in sigs]
-            for k, r in enumerate(recs):
-                pre = r[:int(sp[k]) - 8]
-                post = r[int(sp[k]) + int(sl[k]):]
-                ob = np.frombuffer(out[k], dtype=np.uint8)
-                if lib.press_hip_blow5_write(w, pre.ctypes.data, pre.size, ob.ctypes.data, ob.size,
-                                             post.ctypes.data if post.size else None, post.size):
-                    raise PressError(lib.press_hip_blow5_last_error().decode())
+            _blow5_write_batch(lib, w, [r[:int(sp[k]) - 8] for k, r in enumerate(recs)],
+                               [np.frombuffer(out[k], dtype=np.uint8) for k in range(got.value)],
+                               [r[int(sp[k]) + int(sl[k]):] for k, r in enumerate(recs)])
             total += got.value
     finally:
         rd.close()

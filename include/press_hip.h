@@ -355,7 +355,17 @@ int press_hip_blow5_create(const char *path, const press_hip_blow5 *like, int re
 			   press_hip_blow5_writer **out);
 int press_hip_blow5_write(press_hip_blow5_writer *w, const uint8_t *pre, uint64_t pre_len, const uint8_t *sig,
 			  uint64_t sig_len, const uint8_t *post, uint64_t post_len);
-int press_hip_blow5_finish(press_hip_blow5_writer *w); /* end marker, close, free */
+/* n records at once: framed and deflated by a pool of host threads, written in the order given */
+int press_hip_blow5_write_batch(press_hip_blow5_writer *w, uint32_t n, const uint8_t *const *pre, const uint64_t *pre_len,
+				const uint8_t *const *sig, const uint64_t *sig_len, const uint8_t *const *post,
+				const uint64_t *post_len);
+/* enable != 0: keep slow5lib's index (read id -> record offset and size, slow5_idx.c:269 slow5_idx_write) while
+ * writing; press_hip_blow5_finish leaves it as <path>.idx, so that the reference's slow5_idx_load / slow5_get
+ * (slow5.h:375, 423) find the reads of the file without building the index themselves */
+int press_hip_blow5_index(press_hip_blow5_writer *w, int enable);
+/* host threads that inflate records (reader; 0 = as many as the host offers, at most 32) */
+int press_hip_blow5_threads(press_hip_blow5 *f, int threads);
+int press_hip_blow5_finish(press_hip_blow5_writer *w); /* end marker, the index if asked for, close, free */
 
 #ifdef __cplusplus
 }

@@ -156,14 +156,15 @@ def test_gpu_wide_jumps_and_ragged(oracle):
         assert ro != 0 and rg != 0
 
 
-def _ref_dump(path, tmp_path):
-    """the reference's slow5lib reads `path` (oracle/_ref/ref_dump_blow5) -> {read_id: samples}"""
+def _ref_dump(path, tmp_path, ids=()):
+    """the reference's slow5lib reads `path` (oracle/_ref/ref_dump_blow5) -> {read_id: samples}; with ids: those
+    reads through the index (slow5_idx_load + slow5_get)"""
     import subprocess
     tool = os.path.join(_libs.ORACLE_DIR, "_ref", "ref_dump_blow5")
     if not os.path.exists(tool):
         pytest.skip("oracle/_ref/ref_dump_blow5 is not built here")
     out = str(tmp_path / "dump.bin")
-    subprocess.run([tool, path, out], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([tool, path, out] + list(ids), check=True, stderr=subprocess.DEVNULL)
     d = open(out, "rb").read()
     nreads, = struct.unpack("<I", d[:4])
     p, res = 4, {}
@@ -211,3 +212,56 @@ def test_reframe_without_gpu(tmp_path, rec):
     got = _ref_dump(dst, tmp_path)
     gold = golden_reads()
     assert set(got) == set(gold) and all(np.array_equal(got[k], gold[k]) for k in gold)
+
+
+@pytest.mark.parametrize("rec", [0, 1])
+def test_index_is_the_one_slow5lib_writes(tmp_path, rec):
+    """SURVEY 8f-2 / slow5_idx.c: the writer's <file>.idx lets the reference's slow5_idx_load / slow5_get find reads of
+    a file this library wrote - and it is byte for byte the index slow5lib builds for that file itself"""
+    fields = [f for _, f in parse_blow5_py(BLOW5)]
+    gold = list(golden_reads().values())
+    # 40 records (the three real signals over and over) under ids of their own
+    many = [fields[k % 3] for k in range(40)]
+    dst = str(tmp_path / "indexed.blow5")
+    ids = press.blow5_write_like(dst, BLOW5, many, record_method=rec, signal_method=1, index=True)
+    assert len(ids) == 40 and os.path.exists(dst + ".idx")
+    ours = open(dst + ".idx", "rb").read()
+    assert ours[:9] == b"SLOW5IDX\x01" and ours[-8:] == b"XDI5WOLS"
+    # random access by id, through OUR index
+    pick = [ids[37], ids[0], ids[20], ids[5]]
+    got = _ref_dump(dst, tmp_path, pick)
+    assert list(got) == pick
+    for rid in pick:
+        assert np.array_equal(got[rid], gold[int(rid.split("-")[1]) % 3]), rid
+    assert open(dst + ".idx", "rb").read() == ours  # (slow5lib read it, it did not rebuild it)
+    # ... and the index slow5lib builds when there is none is the same bytes
+    os.remove(dst + ".idx")
+    _ref_dump(dst, tmp_path, pick[:1])
+    assert open(dst + ".idx", "rb").read() == ours
+    # the transcoder writes one too
+    dst2 = str(tmp_path / "t.blow5")
+    assert press.blow5_transcode(BLOW5, dst2, record_method=rec, signal_method=1, passthrough=True, index=True) == 3
+    got = _ref_dump(dst2, tmp_path, [i for i, _ in parse_blow5_py(BLOW5)][::-1])
+    assert len(got) == 3 and all(np.array_equal(got[k], golden_reads()[k]) for k in got)
+
+
+def test_reader_thread_pool_keeps_the_order(tmp_path):
+    """records are inflated by a pool of host threads: the batches come out in file order whatever the pool size and
+    the batch limits, byte for byte"""
+    fields = [f for _, f in parse_blow5_py(BLOW5)]
+    many = [fields[k % 3][: 4 + (len(fields[k % 3]) - 4) // (1 + k % 5)] for k in range(90)]  # (fields of many sizes)
+    # (truncated svb-zd fields are fine for the reader: it hands fields out as stored)
+    dst = str(tmp_path / "many.blow5")
+    ids = press.blow5_write_like(dst, BLOW5, many, record_method=1, signal_method=1)
+    for threads, maxr, arena in ((1, 7, 1 << 24), (4, 64, 1 << 24), (0, 4096, 1 << 24), (3, 50, 600000)):
+        rd = press.Blow5Reader(dst)
+        rd.set_threads(threads)
+        got = []
+        while True:
+            b = rd.next_batch(max_reads=maxr, arena_bytes=arena)
+            if not b:
+                break
+            got += b
+        rd.close()
+        assert [g[0] for g in got] == ids
+        assert [g[2] for g in got] == [bytes(m) for m in many]
