@@ -712,3 +712,32 @@ def test_bench_batch_parity(oracle, m):
     assert not bad, "stream bytes differ from the oracle's for reads %s" % bad[:8]
     diff = np.nonzero(want_len != lens)[0]
     assert diff.size == 0, "out_len differs from the oracle's for %d reads, first %s" % (diff.size, diff[:8])
+
+
+@pytest.mark.parametrize("m", ["vbbe21_zd", "vbsbe21_zd", "vbsse21_zd", "hasgam_vbsse21_zdq", "shuffman_vbbe21_zd",
+                               "shuffman_vbsse21_zd", "vbe21_zd"])
+def test_exception_heavy_sections(oracle, m):
+    """sections with hundreds to tens of thousands of exceptions (the whole wave builds and parses them, 64 per
+    round): every density, position gaps from 0 to 200 000 samples, values from 256 to 65535 - byte parity with the
+    oracle and lossless both ways"""
+    rng = np.random.default_rng(len(m) + 11)
+    cases = []
+    for n, rate, big in ((3000, 0.3, 300), (70000, 0.05, 3000), (70000, 0.9, 20000), (260000, 0.0004, 30000),
+                         (1000, 0.065, 100), (129, 0.5, 50), (40000, 0.3, 32000)):
+        d = rng.integers(-40, 41, size=n)
+        ex = rng.random(n) < rate
+        d[ex] = rng.integers(-big, big + 1, size=int(ex.sum()))
+        cases.append(np.cumsum(d).astype(np.int16))
+    # exactly 64, 65 and 128 exceptions (the rounds' edges)
+    for nex in (64, 65, 128, 2):
+        d = rng.integers(-20, 21, size=20000)
+        at = rng.choice(np.arange(1, 20000), size=nex, replace=False)
+        d[at] = 5000
+        cases.append(np.cumsum(d).astype(np.int16))
+    for sig in cases:
+        if not shuff_ok(m, sig):
+            continue
+        ret, want = oracle.press(m, sig, cap=4 * sig.size + 4096)
+        if ret != 0:
+            continue  # (outside the reference's domain for this method: e.g. the 16-bit section length)
+        check_read(oracle, m, sig, want=want)
