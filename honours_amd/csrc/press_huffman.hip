@@ -1110,6 +1110,10 @@ __device__ __forceinline__ void emit_samples16(const uint8_t *src, const EmitRea
 			auto lowat = [&](uint32_t l) -> uint32_t { return (l >= L0 && l < L1) ? (uint32_t) (int32_t) (int8_t) src[l - L0] : 0u; };
 			gather8(lowat, R.pos, R.val, R.zd0, i0, Ia, Ib, Ea, ecnt, v);
 			gather8(lowat, R.pos, R.val, R.zd0, i0 + 8, Ia, Ib, Ea, ecnt, v + 4);
+			// (this rare path loads exception positions / values it may not use: with such a load possibly pending at
+			// the loop's back edge the compiler put a full vector-memory wait into the PLAIN path of every round - a
+			// wait for the previous round's sample stores.  Nothing of this path is pending behind this line.)
+			__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
 		}
 		const uint32_t ta = lane_prefix8(v) & 0xFFFFu;
 		const uint32_t tb = lane_prefix8(v + 4) & 0xFFFFu;
