@@ -833,12 +833,17 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 #pragma unroll
 	for (int k = 0; k < CK; k++) {
 		const uint32_t i0 = ws + k * SUB + lane * 8;
-		uint2 dd = make_uint2(0, 0);
+		// (a zeroed register pair of its own for every sub-tile: left to itself the compiler kept the two halves of
+		// sub-tile 0 in registers that are no pair, loaded into a third place, copied one half over - and waited for
+		// that load before it issued the other fifteen: two memory round trips per chunk instead of one)
+		unsigned long long d64;
+		asm volatile("v_mov_b64 %0, 0" : "=v"(d64)); // (a register PAIR of its own: the 8-byte load lands in it)
 		if ((plain >> k) & 1u) { // uniform
 			const uint64_t eb = ebase + uni(s_epre[w][k]);
 			if (i0 < n)
-				__builtin_memcpy(&dd, data + eb + i0, 8);
+				__builtin_memcpy(&d64, data + eb + i0, 8);
 		}
+		const uint2 dd = make_uint2((uint32_t) d64, (uint32_t) (d64 >> 32));
 		dat[k] = dd; // (k_low_decode_chunked's unconditional loads were tried here too: 82 instead of 51 VGPRs, 6 % slower)
 	}
 
@@ -1192,19 +1197,25 @@ __global__ __launch_bounds__(CWG, SCAN_WAVES) void k_ex_scan_chunked(BatchArgs a
 	}
 
 	uint32_t kmask = 0, etot = 0, ored32 = 0, zd0 = 0, lbits = 0, nocode = 0;
-	uint32_t carry = 0; // the sample in front of the sub-tile
-	if (ws > 0)
-		carry = (uint32_t) (uint16_t) in[ws - 1] << 16;
 	uint4 raw[4];
 #pragma unroll
 	for (int k = 0; k < 4; k++)
 		raw[k] = sub_load(in, n, ws + k * SUB + lane * 8);
+	// the sample in front of the sub-tile: asked for BEHIND the first sub-tiles (in front of them, its shift made the
+	// wave wait for this one load before it issued any of the others: one more memory round trip per quarter)
+	uint32_t carry = 0, c16 = 0;
+	if (ws > 0)
+		c16 = (uint32_t) (uint16_t) in[ws - 1]; // (shifted into place behind the next group's loads)
 #pragma unroll 1
 	for (int kk = 0; kk < CK; kk += 4) {
 		uint4 nxt[4];
 #pragma unroll
 		for (int k = 0; k < 4; k++)
 			nxt[k] = kk + 4 + k < CK ? sub_load(in, n, ws + (kk + 4 + k) * SUB + lane * 8) : make_uint4(0, 0, 0, 0);
+		if (kk == 0) {
+			asm volatile("" : "+v"(c16)); // (keeps the shift - and the wait for the load - here)
+			carry = c16 << 16;
+		}
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			const uint32_t i0 = ws + (kk + k) * SUB + lane * 8;
@@ -1534,10 +1545,11 @@ __global__ __launch_bounds__(CWG, HENC_WAVES) void k_huff_encode_chunked(BatchAr
 	uint8_t *g = payload + (Bq >> 3); // byte of staging bit 0
 	uint32_t fill = nb;               // bits waiting at the front of the staging buffer
 	wave_lds_sync();
-	uint32_t carry = ws > 0 ? (uint32_t) (uint16_t) in[ws - 1] << 16 : 0u; // the sample in front of the sub-tile
 	uint4 raw[2];
 	raw[0] = sub_load(in, n, ws + lane * 8);
 	raw[1] = sub_load(in, n, ws + SUB + lane * 8);
+	// the sample in front of the sub-tile (behind the loads above: see k_ex_scan_chunked)
+	uint32_t carry = ws > 0 ? (uint32_t) (uint16_t) in[ws - 1] << 16 : 0u;
 #pragma unroll 1
 	for (int k = 0; k < CK; k++) {
 		const uint32_t sub0 = ws + k * SUB;
