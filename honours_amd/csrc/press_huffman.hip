@@ -8,26 +8,25 @@
 // workgroup share the tables and nothing else - no barrier, no wave waits for another:
 //
 //   k_huf_sync   where do codes start?  Lengths (and the sample deltas the symbols stand for - no symbols): one
-//                LDS look-up takes every whole code that fits in 12 bits.  Lane i runs through the RU = OWN/2 bits in front of its subsequence from
-//                their first bit: where that run crosses into its own subsequence is its guess of the
-//                first code's start (right in ~97 % of the cases); then through its own subsequence.
-//                Leaves a record per subsequence {start, codes, sum of their deltas}, where it ended, and
-//                per wave of a tile the totals; lanes whose guess is not where the left neighbour ended
-//                (~3 %) go on a list - nothing is repaired here (a wave repairing the tile's two or three such
-//                lanes while seven others waited at the barrier was a quarter of this kernel) - and so does the
-//                first lane of every quarter, unchecked (its left neighbour is another wave's).
-//                The lane's bits live in a private LDS column (dword j of lane l at j*65 + l + 1; in
-//                k_huf_emit at j*64 + l: any mix of per-lane positions is bank-conflict free); a lane's run-up
-//                reads its neighbour's, the first lane's the column the wave loads in front of its 64.
-//                The loops are wave-uniform with predicated bodies; while 12 bits are left in front of
-//                the limit nothing can step over it, so the body is one look-up fed from a register
-//                window over the column (the dword behind the window is fetched while the look-up is in
-//                flight); the last few codes take a careful loop.
-//                (The first lane of a tile whose left neighbour another workgroup holds is listed unchecked.)
-//   k_huf_fix    the listed subsequences, 64 to a wave - dense, whatever tile they came from: decoded again from
-//                where the subsequence in front ended; the wave totals take the difference (one 64-bit atomic);
-//                if the subsequence's own end moved, its right neighbour goes on the next round's list.  Four
-//                launches; an ordinary table is through after two (900 000 -> 30 000 -> 900 -> 20 entries).
+//                LDS look-up takes every whole code that fits in 12 bits, and its entry is the increment of ONE
+//                accumulator (position, codes, delta sum).  Lane i first runs through the last RU = OWN/2 bits of
+//                its OWN subsequence: where that run crosses into the next subsequence is lane i + 1's guess of its
+//                first code's start (right in ~97 % of the cases; handed over by a lane shuffle); then through its
+//                own subsequence from its guess.  Leaves a record per subsequence {start, codes, sum of their
+//                deltas}, where it ended, per wave of a tile the totals, and ONE 64-bit word per unit: the lanes
+//                whose guess is not where the left neighbour ended (~3 %) and the unit's first lane (no guess: it
+//                starts at bit 0).  Nothing is repaired here.
+//                The lane's bits live in a private LDS column (dword j of lane l at j*64 + l: any mix of per-lane
+//                positions is bank-conflict free).  The lean loops are divergent while-loops (a lane that is through
+//                leaves); while 12 bits are left in front of the limit nothing can step over it, so the body is one
+//                look-up fed from a register window over the column (the dword behind the window is fetched while
+//                the look-up is in flight); the last few codes take a careful loop.
+//   k_huf_list   the words of k_huf_sync -> the dense list of k_huf_fix's first round.
+//   k_huf_fix    the listed subsequences, 64 to a wave - dense, whatever tile they came from: an entry whose guess
+//                was right is dropped; the others are decoded again from where the subsequence in front ended; the
+//                wave totals take the difference (one 64-bit atomic); if the subsequence's own end moved, its right
+//                neighbour goes on the next round's list.  Four launches; an ordinary table is through after two
+//                (1 150 000 -> 30 000 -> 900 -> 20 entries).
 //   k_huf_serial what is listed after that (a code whose lengths share a factor never synchronises): one wave
 //                per such read walks it serially from the first unsettled subsequence - slow, enough for ANY
 //                table and stream; the rounds before it are only faster.
@@ -35,7 +34,9 @@
 //                value there, what the read delivers, and whether k_huf_emit can write its samples.
 //   k_huf_emit   lane i decodes its subsequence once more from its true start, now with the two-symbol
 //                table, into the wave's LDS staging buffer at its final order (scan of the counts); the
-//                count k_huf_sync found ends the loop.  Every wave is on its own (no barrier in the loop).
+//                count k_huf_sync found ends the loop.  Every wave is on its own (no barrier in the loop), and
+//                its loop is a pipeline two units deep: the next unit's payload and records are on their way
+//                while this one is decoded.
 //                The one-byte values do not leave the chip: k_huf_sync also summed the sample deltas they
 //                stand for (per wave, from the same look-up), k_huf_chain made those the sample
 //                value in front of every tile, so the wave turns its staging buffer into samples itself

@@ -1,8 +1,9 @@
 // press_sections.hip - the per-read control kernels of the exception-split methods for gfx950:
 // the header and "u32 nex || exception section" of a read on the encode side, and the parse of
 // the same bytes back into a sorted exception list on the decode side.  Both are a few dozen
-// bytes per read (NA12878: 4.85 exceptions per read, thesis/plots/ex-tab.tex:14) - one lane per
-// read; the sample streams themselves are press_chunked.hip's business.
+// bytes per read on NA12878 (4.85 exceptions per read, thesis/plots/ex-tab.tex:14) - a wave per
+// read, 64 exceptions per round, so that reads with thousands of exceptions cost microseconds too;
+// the sample streams themselves are press_chunked.hip's business.
 // All arithmetic is integer (u8/u16/u32).
 
 #include <stdlib.h>
@@ -17,8 +18,8 @@ constexpr uint64_t FAIL64 = ~0ull;
 // ------------------------------------------------------------------ exception split: section builder
 //
 // Writes the header and "u32 nex || section" of one read and decides whether the read
-// fits its slot.  One wave per read; lane 0 does the (tiny: ~5 exceptions per read on
-// NA12878, thesis/plots/ex-tab.tex:14) serial work.
+// fits its slot.  One wave per read: lane 0 writes the header fields, the whole wave the two
+// coded blocks.
 //   vbe21   press.c:2707-2716        vbbe21  press.c:2826-2872 (bit-pack press.c:285-397)
 //   vbsbe21 press.c:3028-3082        vbsse21 press.c:3232-3276   ex-zd ex_zd.c:83-154
 
