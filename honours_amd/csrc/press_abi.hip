@@ -506,7 +506,7 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 	if (is_svb(method) || is_ex(method)) {
 		const size_t mc = max_chunks_of(total_samples, nreads);
 		if (g.chunks.reserve(mc * sizeof(ChunkDesc)) || g.gran.reserve(2 * mc * sizeof(uint64_t)) ||
-		    g.ctl.reserve(sizeof(ChunkCtl)) || g.first_chunk.reserve(((size_t) nreads + 1) * 4))
+		    g.ctl.reserve(2 * sizeof(ChunkCtl)) || g.first_chunk.reserve(((size_t) nreads + 1) * 4))
 			return PRESS_HIP_EHIP;
 	}
 	if (is_ex(method)) {

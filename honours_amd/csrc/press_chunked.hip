@@ -2081,8 +2081,7 @@ void launch_ex_decode_chunked(const DecodeArgs &a, int fmt, int ent, hipStream_t
 	const bool huff = ent != 0; // the one-byte stream comes from a.low (Huffman or range decoder)
 	if (!a.nreads || !a.max_chunks)
 		return;
-	launch_ex_parse_huff(a, fmt, ent, s);
-	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
+	launch_ex_parse_huff(a, fmt, ent, s); // (k_ex_parse clears both control blocks)
 	hipLaunchKernelGGL(k_chunk_prep_meta, dim3((a.nreads + 255) / 256), dim3(256), 0, s, a.off, a.in_off,
 			   a.meta, a.nreads, a.chunks, a.gran, a.ctl, a.max_chunks, a.out_n,
 			   ent == 1 ? (const uint32_t *) a.hread : (const uint32_t *) nullptr);

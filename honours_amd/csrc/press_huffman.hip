@@ -1597,11 +1597,12 @@ static void run_huff_decode_t(const DecodeArgs &a, bool trie, hipStream_t s)
 
 // Huffman stage of the exception-split decoders: payload of every read -> a.low.  minlen: the table's shortest code
 // (selects the subsequence size) | HUF_NEEDS_TRIE if some code is beyond the second-level tables
-void launch_huff_decode(const DecodeArgs &a, uint32_t minlen, hipStream_t s)
+void launch_huff_decode(const DecodeArgs &a0, uint32_t minlen, hipStream_t s)
 {
 	const bool trie = (minlen & HUF_NEEDS_TRIE) != 0;
 	minlen &= ~HUF_NEEDS_TRIE;
-	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
+	DecodeArgs a = a0;
+	a.ctl = a0.ctl + 1; // the decoder's own control block (cleared by k_ex_parse, the first kernel of the call)
 	hipLaunchKernelGGL(k_huff_tiles, dim3((a.nreads + TILES_RPW - 1) / TILES_RPW), dim3(64), 0, s, a);
 	if (minlen >= 4)
 		run_huff_decode_t<128>(a, trie, s);

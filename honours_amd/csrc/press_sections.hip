@@ -395,6 +395,14 @@ __global__ __launch_bounds__(64) void k_ex_parse(DecodeArgs a, int fmt, int huff
 		m->nex = 0;
 		m->q = 0;
 	}
+	// the two control blocks of the decode call (a.ctl[0]: the chunk table of k_chunk_prep_meta .. k_low_decode_chunked,
+	// a.ctl[1]: the Huffman decoder's tiles, lists and tickets) are cleared here, by the first kernel of the call - two
+	// hipMemsetAsync between the kernels were 10 us each
+	if (r == 0) {
+		uint32_t *c = reinterpret_cast<uint32_t *>(a.ctl);
+		for (uint32_t i = lane; i < 2 * sizeof(ChunkCtl) / 4; i += 64)
+			c[i] = 0;
+	}
 	if (len < (uint64_t) hdr + 4 || cap == 0)
 		return;
 	uint32_t mq = 0, zd0;
