@@ -767,7 +767,11 @@ __global__ __launch_bounds__(HT) void k_huf_chain(DecodeArgs a)
 
 // ------------------------------------------------------------------ k_huf_emit
 
-constexpr uint32_t EMIT_STG = 3328; // staging bytes per wave: 52 per lane (NA12878: 47.4 on average, 64 at most)
+// staging bytes per wave: 64 per lane - a subsequence holds at most 64 codes (OWN bits / the shortest code), so the buffer
+// takes whatever the wave decodes.  (With 52 per lane - NA12878 averages 47.4 - a unit with more symbols went a slow way
+// through global memory; low-entropy stretches such as a read's stall, 1 % of the samples with 4-bit codes throughout,
+// cost 17 % of the decode time, a whole batch of them 9 x: tools/lowent.py.)
+constexpr uint32_t EMIT_STG = 4096;
 
 // The first nmine codes from bit p of the column on: the DELTA each symbol stands for (zig-zag undone, one
 // signed byte) to wp[0 ..] (LDS staging or the one-byte stream's place).  k_huf_sync counted the codes that
@@ -779,7 +783,7 @@ constexpr uint32_t EMIT_STG = 3328; // staging bytes per wave: 52 per lane (NA12
 // counter).  Both bytes of an entry are always stored: while the count has room for two, the second slot is the
 // lane's own, and a one-code entry's second byte is overwritten by the lane's next store.  The position runs 30 bits
 // ahead, so that the window bits sit at bits 2 .. 13 of the funnel shift: masked, they are the table's byte offset.
-template <bool TRIE, bool LDSOUT>
+template <bool TRIE>
 __device__ __forceinline__ void emit_codes(const uint32_t *col_, const uint32_t *lut_, const uint16_t *lut2_,
 					   const HuffDev *hd, uint32_t p, uint32_t nmine, uint8_t *wp_)
 {
@@ -796,7 +800,7 @@ __device__ __forceinline__ void emit_codes(const uint32_t *col_, const uint32_t 
 		const uint32_t e2 = lut2[(e & 0xFFFu) + ((wnd >> HUF_LUT_BITS) & ((1u << ((e >> 12) & 15u)) - 1u))];
 		return e2 == 0xFFFFu ? 0u : (((uint32_t) unzz8(e2 & 0xFFu) & 0xFFu) | (e2 & 0x1F00u) | ((e2 & 0x1F00u) << 16));
 	};
-	typedef typename std::conditional<LDSOUT, lds_u8p, uint8_t *>::type WP;
+	typedef lds_u8p WP; // (the wave's staging buffer)
 	WP w = (WP) wp_;
 	const WP wend = w + nmine;
 	WP wlim = nmine ? wend - 1 : w; // a step needs room for two: w < wlim
@@ -986,84 +990,8 @@ __device__ __forceinline__ EmitPlan emit_plan(const EmitRead &R, uint32_t L0, ui
 	return P;
 }
 
-// The deltas of the wave's values [L0, L1) are in src (LDS staging: src[l - L0]; or, GLOBAL, the place of
-// the read's one-byte stream: src[l]): write the samples they and their exceptions make.
-template <bool GLOBAL>
-__device__ __forceinline__ void emit_samples(const uint8_t *src, const EmitRead &R, const EmitPlan &P, uint32_t lane)
-{
-	const uint32_t L0 = P.L0, L1 = P.L1, Ea = P.Ea, ecnt = P.ecnt, Ia = P.Ia, Ib = P.Ib, pe = P.pe;
-	uint32_t base = P.base;
-	auto ex_below = [&](uint32_t key) -> uint32_t { // exceptions of the wave with pos < key
-		if (ecnt == 0)
-			return 0u;
-		if (ecnt <= 64)
-			return (uint32_t) __popcll(__ballot(pe < key));
-		return uniform(lower_bound_u32(R.pos + Ea, ecnt, key));
-	};
-	const bool shift = uniform(R.q) != 0;
-	const u16x2 qq = { (unsigned short) R.q, (unsigned short) R.q };
-	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(src);
-	// 512 samples at a time, 8 per lane, in groups that start at multiples of EMIT_ALIGN samples; the
-	// first and the last round are ragged
-	for (uint32_t g = Ia & ~(EMIT_ALIGN - 1); g < Ib; g += 512) {
-		const uint32_t i0 = g + lane * 8;
-		// exceptions in front of sample g / of sample g + 512
-		const uint32_t e0 = ex_below(g ? g - 1 : 0u), e1 = ex_below(g + 511);
-		const bool plain = !GLOBAL && e0 == e1 && g != 0;
-		const bool ragged = g < Ia || g + 512 > Ib;
-		uint32_t v[4];
-		if (plain) {
-			// sample i = value number i - 1 - (Ea + e0)
-			const bool any = i0 + 8 > Ia && i0 < Ib;
-			const int32_t o = any ? (int32_t) (i0 - 1 - Ea - e0 - L0) : 0; // >= -8 (the staging buffers have room in front)
-			const int32_t j = o >> 2;
-			const uint32_t sh = (uint32_t) (o & 3) * 8u; // (the same in every lane)
-			const uint32_t d0 = s32[j], d1 = s32[j + 1], d2 = s32[j + 2];
-			uint2 dd = make_uint2(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh));
-			if (ragged) {
-				const uint32_t lo = Ia > i0 ? (Ia - i0 < 8 ? Ia - i0 : 8u) : 0u;
-				const uint32_t hi = Ib > i0 ? (Ib - i0 < 8 ? Ib - i0 : 8u) : 0u;
-				uint64_t m = hi >= 8 ? ~0ull : ((1ull << (8 * hi)) - 1ull);
-				m &= lo >= 8 ? 0ull : ~((1ull << (8 * lo)) - 1ull);
-				dd.x &= (uint32_t) m;
-				dd.y &= (uint32_t) (m >> 32);
-			}
-			expand8s(dd, v);
-		} else if (GLOBAL) {
-			gather8([&](uint32_t l) -> uint32_t {
-					return (l >= L0 && l < L1) ? (uint32_t) (int32_t) (int8_t) __hip_atomic_load(src + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-				}, R.pos, R.val, R.zd0, i0, Ia, Ib, Ea, ecnt, v);
-		} else {
-			gather8([&](uint32_t l) -> uint32_t { return (l >= L0 && l < L1) ? (uint32_t) (int32_t) (int8_t) src[l - L0] : 0u; },
-				R.pos, R.val, R.zd0, i0, Ia, Ib, Ea, ecnt, v);
-		}
-		const uint32_t tot = lane_prefix8(v) & 0xFFFFu;
-		const uint32_t inc = wave_incl_scan_dpp(tot);
-		const uint32_t b16 = (base + inc - tot) & 0xFFFFu;
-		const uint32_t b2 = b16 | (b16 << 16);
-#pragma unroll
-		for (int h = 0; h < 4; h++)
-			v[h] = pk_add16(v[h], b2);
-		if (shift) { // ex_zd.c:396 do_rev_qts_inplace
-#pragma unroll
-			for (int h = 0; h < 4; h++)
-				v[h] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, v[h]) << qq);
-		}
-		if (!ragged || (i0 >= Ia && i0 + 8 <= Ib)) {
-			const uint4 vv = make_uint4(v[0], v[1], v[2], v[3]);
-			__builtin_memcpy(R.out + i0, &vv, 16);
-		} else {
-#pragma unroll
-			for (uint32_t h = 0; h < 8; h++)
-				if (i0 + h >= Ia && i0 + h < Ib)
-					R.out[i0 + h] = (int16_t) (v[h >> 1] >> (16 * (h & 1)));
-		}
-		base += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
-	}
-}
-
-// The same from the LDS staging buffer with 16 samples per lane and round (1024 per round): half the wave scans
-// and half the rounds of emit_samples; a lane's two groups of 8 are what emit_samples gives two lanes.
+// The deltas of the wave's values [L0, L1) are in the LDS staging buffer (src[l - L0]): write the samples they and
+// their exceptions make, 16 samples per lane and round (1024 per round; 8 per lane cost twice the wave scans and rounds).
 __device__ __forceinline__ void emit_samples16(const uint8_t *src, const EmitRead &R, const EmitPlan &P, uint32_t lane)
 {
 	const uint32_t L0 = P.L0, L1 = P.L1, Ea = P.Ea, ecnt = P.ecnt, Ia = P.Ia, Ib = P.Ib, pe = P.pe;
@@ -1382,7 +1310,10 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 		const uint32_t ex = inc - cnt; // codes of the wave in front of this lane
 		const uint32_t f = rec & 0xFFu;
 		const uint32_t p0 = f == R_END ? 0u : f;
-		const uint32_t nmine = (ex >= quota || f == R_END) ? 0u : (cnt < quota - ex ? cnt : quota - ex);
+		uint32_t nmine = (ex >= quota || f == R_END) ? 0u : (cnt < quota - ex ? cnt : quota - ex);
+		// (at most 64 codes per lane: the staging buffer takes them all; the clamp only keeps records that are not
+		// this library's own from writing outside it)
+		nmine = ex >= EMIT_STG ? 0u : (nmine < EMIT_STG - ex ? nmine : EMIT_STG - ex);
 		uint8_t *dst = low + obase;
 		EmitRead R = {};
 		if (fused) {
@@ -1395,19 +1326,18 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 			R.nlow = uniform(S.m1.z); // ::nlow
 		}
 		(void) tid;
-		// symbols go to the wave's staging buffer in their final order; a wave that holds more codes than
-		// the buffer takes (cannot happen with 5.4-bit codes on average) stores them byte by byte instead
+		// symbols go to the wave's staging buffer in their final order
 		// (the read's first exceptions: asked for now, needed behind the decode loop)
 		// (the position as loaded: any arithmetic on it here would put the wait for it - and for every load issued before
 		// it, the next unit's among them - in front of the decode loop)
 		const uint32_t kraw = (fused && quota && lane < R.nex) ? R.pos[lane] : 0xFFFFFFFFu;
 		const uint32_t vraw = (fused && quota && lane < R.nex) ? R.val[lane] : 0u; // (their values and delta prefixes)
 		HSTAMP(2); // scan, read record
-		if (wsum <= EMIT_STG) {
+		{
 #if defined(EMIT_ABL) && EMIT_ABL == 3 // (timing experiments only: wrong results)
 			if (a.nreads == 0x7FFFFFFFu)
 #endif
-			emit_codes<TRIE, true>(col, lut, lut2, a.huff, p0, nmine, stg + ex);
+			emit_codes<TRIE>(col, lut, lut2, a.huff, p0, nmine, stg + ex);
 			HSTAMP(3); // decode
 			// what was asked for at the top has arrived (the columns are free, and no store of this unit is in the way)
 			if (more)
@@ -1442,22 +1372,6 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 				}
 			}
 			wave_lds_sync(); // staging is free again
-		} else {
-			emit_codes<TRIE, false>(col, lut, lut2, a.huff, p0, nmine, dst + ex);
-			if (more)
-				land2(Un, Sn);
-			if (u_nn < nunits)
-				Unn = resolve(u_nn, tv_nn);
-			if (fused && quota) {
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the wave reads back what its lanes wrote
-				__builtin_amdgcn_wave_barrier();
-				emit_samples<true>(low, R, emit_plan(R, (uint32_t) obase, quota, B0, lane, kraw, vraw), lane);
-			} else if (!fused) {
-				for (uint32_t b = 0; b < nmine; b++) { // deltas -> one-byte values, in place
-					const uint32_t dl = dst[ex + b];
-					dst[ex + b] = (uint8_t) ((dl << 1) ^ (0u - (dl >> 7)));
-				}
-			}
 		}
 		HSTAMP(6); // (the rest of a unit)
 		if (!more)

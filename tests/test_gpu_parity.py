@@ -741,3 +741,29 @@ def test_exception_heavy_sections(oracle, m):
         if ret != 0:
             continue  # (outside the reference's domain for this method: e.g. the 16-bit section length)
         check_read(oracle, m, sig, want=want)
+
+
+def test_huffman_low_entropy_stretches(oracle):
+    """a read's low-noise stretches (a nanopore "stall") code every sample with the table's shortest codes: 64 codes per
+    256-bit subsequence, 4096 per wave - the emit kernel's staging buffer takes them all (it used to hold 3328 and send
+    the rest a slow way).  Byte parity and both decode ways, on reads that are all / partly / not at all low entropy."""
+    rng = np.random.default_rng(17)
+    lens = oracle.table()
+    short = [s for s in range(256) if lens[s][0] == min(l for l, _ in lens)]
+    assert short, "the table has a shortest code"
+    reads = []
+    for n, frac in ((70000, 1.0), (70000, 0.3), (150000, 0.05), (33000, 1.0), (9000, 0.0)):
+        d = rng.integers(-30, 31, size=n)
+        k = int(n * frac)
+        # zig-zag values with the shortest codes only
+        z = rng.choice(short, size=k)
+        d[:k] = (z >> 1) ^ -(z & 1)
+        d[0] = 500
+        reads.append(np.cumsum(d).astype(np.int16))
+    for sig in reads:
+        check_read(oracle, "shuffman_vbe21_zd", sig)
+    st = press.press_batch_host("shuffman_vbe21_zd", reads)
+    for s, got in zip(reads, st):
+        assert got == oracle.press("shuffman_vbe21_zd", s)[1]
+    back = press.depress_batch_host("shuffman_vbe21_zd", st, [len(s) for s in reads])
+    assert all(b is not None and np.array_equal(b, s) for b, s in zip(back, reads))
