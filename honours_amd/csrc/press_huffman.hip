@@ -132,6 +132,35 @@ __device__ __forceinline__ uint32_t clamp_nb(int64_t v)
 	return v <= 0 ? 0u : (v > 0x7FFFFFFF ? 0x7FFFFFFFu : (uint32_t) v);
 }
 
+// 16 / 4 payload bytes at any byte address; the payload is streamed (k_huf_sync and k_huf_emit each read it once, far
+// apart): non-temporal policy (tools/ubench_stream.hip)
+#ifndef HUF_NO_NT
+__device__ __forceinline__ uint4 ld16_pay(const uint8_t *p)
+{
+	typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+	const u32x4_u v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(p));
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t ld4_pay(const uint8_t *p)
+{
+	typedef uint32_t __attribute__((aligned(1))) u32_u;
+	return __builtin_nontemporal_load(reinterpret_cast<const u32_u *>(p));
+}
+#else
+__device__ __forceinline__ uint4 ld16_pay(const uint8_t *p)
+{
+	uint4 v;
+	__builtin_memcpy(&v, p, 16);
+	return v;
+}
+__device__ __forceinline__ uint32_t ld4_pay(const uint8_t *p)
+{
+	uint32_t v;
+	__builtin_memcpy(&v, p, 4);
+	return v;
+}
+#endif
+
 // Stage NDW dwords of the tile from byte offset rb0 (a multiple of 4, possibly negative: the
 // run-up of a tile's first lane lies in the previous tile) into a column.  Bytes outside
 // the payload [lo, nby) read as zero.  Lanes whose dwords all lie inside issue their loads back
@@ -145,10 +174,10 @@ __device__ __forceinline__ void col_load(uint32_t *col, const uint8_t *src, int3
 		uint32_t x[NDW % 4 ? NDW % 4 : 1];
 #pragma unroll
 		for (int j = 0; j < NDW / 4; j++)
-			__builtin_memcpy(&t[j], q + 16 * j, 16);
+			t[j] = ld16_pay(q + 16 * j);
 #pragma unroll
 		for (int j = 0; j < NDW % 4; j++)
-			__builtin_memcpy(&x[j], q + 4 * (NDW / 4 * 4 + j), 4);
+			x[j] = ld4_pay(q + 4 * (NDW / 4 * 4 + j));
 #pragma unroll
 		for (int j = 0; j < NDW / 4; j++) {
 			col[(4 * j + 0) * S] = t[j].x;
@@ -1245,10 +1274,10 @@ __global__ __launch_bounds__(WGE) void k_huf_emit(DecodeArgs a)
 			uint4 t[NDW / 4 ? NDW / 4 : 1];
 #pragma unroll
 			for (int j = 0; j < NDW / 4; j++)
-				__builtin_memcpy(&t[j], q + 16 * j, 16);
+				t[j] = ld16_pay(q + 16 * j);
 #pragma unroll
 			for (int j = 0; j < NDW % 4; j++)
-				__builtin_memcpy(&S.pay[NDW / 4 * 4 + j], q + 4 * (NDW / 4 * 4 + j), 4);
+				S.pay[NDW / 4 * 4 + j] = ld4_pay(q + 4 * (NDW / 4 * 4 + j));
 #pragma unroll
 			for (int j = 0; j < NDW / 4; j++) {
 				S.pay[4 * j + 0] = t[j].x;
