@@ -294,13 +294,23 @@ __global__ __launch_bounds__(256) void k_chunk_prep(const uint64_t *off, const u
 
 // S5 (with KEY2, ZD): slow5lib's "svb-zd" signal codec (slow5_press.c:1054): a u32 sample count
 // in front, and the delta taken in 32 bits - a jump of more than 32767 is a 3-byte value.
-template <bool KEY2, bool ZD, bool S5 = false>
+// HIST (the zstd compositions, press_zstd.hip): the data bytes are counted per read (BatchArgs::zhist) while a lane
+// holds them - the Huffman table of the read's frame needs their histogram, and a kernel of its own read the stream again
+// for it (0.36 ms of config 3's press call).  16 copies of the counters in LDS (4 per wave, by lane): nanopore deltas
+// are peaked, and lanes that hit one counter in one instruction are served one after the other.
+template <bool KEY2, bool ZD, bool S5 = false, bool HIST = false>
 __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 {
 	static_assert(!S5 || (KEY2 && ZD), "the slow5 variant is svb32 of zig-zag deltas");
+	static_assert(!HIST || !S5, "the histogram is for the two-byte formats");
 	__shared__ uint32_t s_ticket;
 	__shared__ uint32_t s_wtot[4];
 	__shared__ uint64_t s_excl;
+	__shared__ uint32_t s_hist[HIST ? 16 : 1][256];
+	uint32_t *myhist = s_hist[HIST ? 4 * (threadIdx.x >> 6) + (threadIdx.x & 3) : 0];
+	if (HIST)
+		for (int i = 0; i < 16; i++)
+			s_hist[i][threadIdx.x] = 0; // (the ticket barrier orders this in front of every count)
 
 	// persistent workgroups: chunks are handed out in ticket order (what makes the
 	// look-back deadlock free).  (Fetching the next ticket early was measured slower.)
@@ -463,6 +473,13 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 				v.x = lo0;
 				v.y = lo1;
 				__builtin_memcpy(data + ebase + i0, &v, 8);
+				if (HIST) {
+#pragma unroll
+					for (int e = 0; e < 4; e++) {
+						atomicAdd(&myhist[(lo0 >> (8 * e)) & 0xFFu], 1u);
+						atomicAdd(&myhist[(lo1 >> (8 * e)) & 0xFFu], 1u);
+					}
+				}
 			}
 			continue;
 		}
@@ -509,6 +526,17 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 				if (nv > 4)
 					out[(i0 >> 2) + 1] = (uint8_t) k1;
 			}
+			if (HIST) {
+#pragma unroll
+				for (int q = 0; q < 8; q++) {
+					if ((uint32_t) q < nv) {
+						const uint32_t val = (zz[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+						atomicAdd(&myhist[val & 0xFFu], 1u);
+						if (val > 255u)
+							atomicAdd(&myhist[val >> 8], 1u);
+					}
+				}
+			}
 			if (nv == 8 && cnt == 0) {
 				uint2 v;
 				v.x = lo0;
@@ -531,6 +559,17 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 			}
 		}
 		ebase += tot;
+	}
+	if (HIST) { // the chunk's counts to its read's; a thread clears what it has read (the next chunk counts behind
+		    // three barriers)
+		__syncthreads();
+		uint32_t c = 0;
+		for (int i = 0; i < 16; i++) {
+			c += s_hist[i][threadIdx.x];
+			s_hist[i][threadIdx.x] = 0;
+		}
+		if (c)
+			atomicAdd(&a.zhist[(uint64_t) d.read * 256 + threadIdx.x], c);
 	}
 	} // ticket loop
 }
@@ -2026,7 +2065,7 @@ __global__ __launch_bounds__(CWG) void k_low_decode_chunked(DecodeArgs a)
 
 // ------------------------------------------------------------------ launchers
 
-template <bool KEY2, bool ZD, bool S5 = false>
+template <bool KEY2, bool ZD, bool S5 = false, bool HIST = false>
 static void run_encode(const BatchArgs &a, hipStream_t s)
 {
 	(void) hipMemsetAsync(a.ctl, 0, sizeof(ChunkCtl), s);
@@ -2037,7 +2076,7 @@ static void run_encode(const BatchArgs &a, hipStream_t s)
 	// persistent grid: as many workgroups as are resident (4 per CU)
 	const uint32_t grid = a.max_chunks < PERSISTENT_GRID ? a.max_chunks : PERSISTENT_GRID;
 	ktime_begin(0, s);
-	hipLaunchKernelGGL((k_svb_encode_chunked<KEY2, ZD, S5>), dim3(grid), dim3(CWG), 0, s, a);
+	hipLaunchKernelGGL((k_svb_encode_chunked<KEY2, ZD, S5, HIST>), dim3(grid), dim3(CWG), 0, s, a);
 	ktime_end(0, s);
 }
 
@@ -2047,6 +2086,10 @@ void launch_svb_encode_chunked(const BatchArgs &a, bool key2bit, bool zd, hipStr
 		return;
 	if (slow5)
 		run_encode<true, true, true>(a, s);
+	else if (a.zhist && key2bit)
+		run_encode<true, true, false, true>(a, s);
+	else if (a.zhist)
+		run_encode<false, true, false, true>(a, s);
 	else if (key2bit)
 		run_encode<true, true>(a, s);
 	else if (zd)

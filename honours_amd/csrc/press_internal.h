@@ -145,6 +145,8 @@ struct BatchArgs {
 	ChunkBits *cbits;         // [max_chunks] Huffman code-bit counts (NULL for the other methods)
 	uint8_t *low_tmp;         // range-coder methods: the one-byte values of read r at low_tmp[off[r]..] (else NULL)
 	uint32_t *first_chunk;    // [nreads] id of the first chunk of read r (exception-split encode)
+	uint32_t *zhist;          // zstd compositions: [nreads][256] occurrences of the data bytes, counted where the svb
+	                          // encoder has them in registers (zeroed by the caller; NULL for the other methods)
 };
 
 struct HufTile {             // one tile of a read's Huffman payload (press_huffman.hip), 32 bytes

@@ -815,6 +815,8 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 	sv.out = z.ztmp;
 	sv.out_off = z.kdiv ? z.zoff4 : z.zoff;
 	sv.out_len = z.zlen;
+	(void) hipMemsetAsync(z.hist, 0, (size_t) a.nreads * 1024, s);
+	sv.zhist = z.kdiv ? z.hist : nullptr; // svb: the data bytes are counted where they are made
 	ktime_mute(true);
 	if (z.kdiv)
 		launch_svb_encode_chunked(sv, z.kdiv == 4, true, s);
@@ -825,8 +827,8 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 			   z.max_blocks, z.kdiv, z.ztmp, z.zoff, a.meta);
 	hipLaunchKernelGGL(k_zs_blockmap, dim3((z.max_blocks + 255) / 256), dim3(256), 0, s, z.first_blk, a.nreads, z.nblocks,
 			   z.blk_read);
-	(void) hipMemsetAsync(z.hist, 0, (size_t) a.nreads * 1024, s);
-	hipLaunchKernelGGL(k_zs_hist, dim3(z.max_blocks), dim3(256), 0, s, z);
+	if (!z.kdiv) // (the exception-split stream: counted from ztmp)
+		hipLaunchKernelGGL(k_zs_hist, dim3(z.max_blocks), dim3(256), 0, s, z);
 	hipLaunchKernelGGL(k_zs_keycount, dim3(a.max_chunks), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_table, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_keylist, dim3(a.max_chunks), dim3(256), 0, s, a, z);
@@ -1087,6 +1089,32 @@ __global__ __launch_bounds__(256) void k_zs_copy(DecodeArgs a, ZsBufs z)
 		copy_piece(a, z, z.dcopy[i]);
 }
 
+#ifdef HUF_STAMPS
+// diagnostic build only (tools/zsstamps.py): s_memtime differences of a wave of k_zs_hdecode, summed per phase
+__device__ unsigned long long g_zstamp[8];
+#define ZSTAMP_DECL                                             \
+	unsigned long long zs_t = __builtin_amdgcn_s_memtime(); \
+	unsigned long long zs_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
+#define ZSTAMP(i)                                                              \
+	do {                                                                   \
+		__builtin_amdgcn_sched_barrier(0);                             \
+		const unsigned long long zs_n = __builtin_amdgcn_s_memtime(); \
+		zs_acc[(i) & 7] += zs_n - zs_t;                                \
+		zs_t = zs_n;                                                   \
+		__builtin_amdgcn_sched_barrier(0);                             \
+	} while (0)
+#define ZSTAMP_FLUSH()                                                   \
+	do {                                                             \
+		if ((threadIdx.x & 63) == 0)                             \
+			for (int zs_i = 0; zs_i < 8; zs_i++)             \
+				atomicAdd(&g_zstamp[zs_i], zs_acc[zs_i]); \
+	} while (0)
+#else
+#define ZSTAMP_DECL
+#define ZSTAMP(i)
+#define ZSTAMP_FLUSH()
+#endif
+
 constexpr uint32_t HD_SYMS = 64; // bytes decoded per round (32: 2.06 ms, 64: 1.92 ms)
 constexpr uint32_t HD_IN = 96;   // stream bytes staged per round: 64 codes of at most 11 bits, 11 more, whole bytes
 // one wave per PAIR of units (a unit = up to ZU blocks of one read = 32 streams; the mean read has
@@ -1103,6 +1131,7 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	if (2 * blockIdx.x >= total)
 		return;
 	const int lane = threadIdx.x;
+	ZSTAMP_DECL;
 	uint32_t tlh[2] = { 0, 0 }, cnth[2] = { 0, 0 }, readh[2] = { 0, 0 };
 	for (int hh = 0; hh < 2; hh++) {
 		const uint32_t uu = 2 * blockIdx.x + hh;
@@ -1157,6 +1186,7 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 		readh[hh] = un.read;
 	}
 	__syncthreads();
+	ZSTAMP(0); // tables
 	const int half = lane >> 5;
 	const uint32_t u = 2 * blockIdx.x + half;
 	const uint32_t tl = half ? tlh[1] : tlh[0];
@@ -1218,6 +1248,7 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	uint32_t *myout = sout[lane];
 	myin[0] = 0; // stream byte base + j of a round sits at slot byte 4 + j: bits "below the stream" read as zeros
 	const uint32_t tsh = 11 - tl;
+	ZSTAMP(1); // stream headers
 	for (uint32_t done = 0; __any(active && done < k); done += HD_SYMS) {
 		const bool go = active && done < k;
 		const uint32_t cnt = go ? (k - done < HD_SYMS ? k - done : HD_SYMS) : 0;
@@ -1261,6 +1292,7 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 				myin[at >> 2] = (myin[at >> 2] & ~(0xFFu << (8 * (at & 3)))) | (b << (8 * (at & 3)));
 			}
 		}
+		ZSTAMP(2); // staging
 		uint32_t acc = 0;
 		const int32_t c0 = 32 - 11 - 8 * base; // slot bit of stream bit b: b + 32 - 8 base
 		// the two dwords around slot bit bp + c0 stay in registers; the dword below them is fetched while
@@ -1290,6 +1322,7 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 		}
 		if (cnt & 3)
 			myout[cnt >> 2] = acc;
+		ZSTAMP(3); // decode
 		// ---- the round's bytes out: four lanes share a stream's 64 bytes, 16 each, so that a
 		// store instruction writes 16 runs of 64 bytes instead of 64 scattered dwords (which cost
 		// as much as all the decoding: measured)
@@ -1315,7 +1348,9 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 					out[done + e] = (uint8_t) (myout[e >> 2] >> (8 * (e & 3)));
 		}
 		__builtin_amdgcn_wave_barrier();
+		ZSTAMP(4); // stores
 	}
+	ZSTAMP_FLUSH();
 	if (active)
 		ok = bp == 0 && !overrun; // the stream ends exactly here
 	{
@@ -1471,3 +1506,14 @@ void launch_zstd_decode_streams(const DecodeArgs &a, const ZsBufs &z, hipStream_
 }
 
 } // namespace ph
+
+#ifdef HUF_STAMPS
+extern "C" int press_hip_zs_stamps(unsigned long long *dst)
+{
+	unsigned long long z[8] = { 0 };
+	if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(dst, HIP_SYMBOL(ph::g_zstamp), sizeof z) != hipSuccess ||
+	    hipMemcpyToSymbol(HIP_SYMBOL(ph::g_zstamp), z, sizeof z) != hipSuccess)
+		return -1;
+	return 0;
+}
+#endif
