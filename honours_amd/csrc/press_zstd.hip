@@ -345,7 +345,6 @@ struct WavePar {
 
 // one wave per read: the Huffman table from the histogram, and the ranks of the key lists
 struct TabLds {
-	uint32_t cnt[256];
 	uint8_t order[256];
 	zs::Table t;
 	zs::Work k;
@@ -361,6 +360,9 @@ __global__ __launch_bounds__(256) void k_zs_table(BatchArgs a, ZsBufs z)
 	if (rd->mode)
 		return;
 	TabLds &L = lds[w];
+	// the counts live where build_table keeps the nodes' parents: it reads them (into Work::w) before it writes those
+	static_assert(sizeof(L.k.parent) >= 256 * sizeof(uint32_t) && offsetof(zs::Work, parent) % 4 == 0, "counts in Work::parent");
+	uint32_t *cnt = reinterpret_cast<uint32_t *>(L.k.parent);
 	// ---- ranks of the key lists
 	{
 		const uint32_t n = a.nsamp[r];
@@ -396,13 +398,13 @@ __global__ __launch_bounds__(256) void k_zs_table(BatchArgs a, ZsBufs z)
 		present = 2;
 	}
 	for (int i = 0; i < 4; i++)
-		L.cnt[lane + 64 * i] = mine[i];
+		cnt[lane + 64 * i] = mine[i];
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	uint32_t rank[4] = { 0, 0, 0, 0 };
 	for (uint32_t s = 0; s < 256; s++) {
-		const uint32_t c = L.cnt[s];
+		const uint32_t c = cnt[s];
 		if (!c)
 			continue;
 		for (int i = 0; i < 4; i++) {
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(256) void k_zs_table(BatchArgs a, ZsBufs z)
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-	zs::build_table(L.cnt, L.order, present, L.t, L.k, WavePar{ (uint32_t) lane });
+	zs::build_table(cnt, L.order, present, L.t, L.k, WavePar{ (uint32_t) lane });
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -882,6 +884,17 @@ struct DevSink {
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	}
+#ifdef HUF_STAMPS
+	unsigned long long st_t = 0, st_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+	__device__ void stamp(int i)
+	{
+		__builtin_amdgcn_sched_barrier(0);
+		const unsigned long long n = __builtin_amdgcn_s_memtime();
+		st_acc[i] += n - st_t;
+		st_t = n;
+		__builtin_amdgcn_sched_barrier(0);
+	}
+#endif
 	// frame bytes for the walk: the lanes share the loads
 	__device__ void fetch(uint8_t *dst, const uint8_t *src, uint32_t n)
 	{
@@ -1015,6 +1028,34 @@ struct DevSink {
 	}
 };
 
+#ifdef HUF_STAMPS
+// diagnostic build only (tools/zsstamps.py): s_memtime differences of a wave of k_zs_hdecode, summed per phase
+__device__ unsigned long long g_zstamp[8];
+__device__ unsigned long long g_wstamp[8];
+__device__ uint32_t g_walk_ticks[8192]; // k_zs_walk: s_memtime ticks of read r's wave
+#define ZSTAMP_DECL                                             \
+	unsigned long long zs_t = __builtin_amdgcn_s_memtime(); \
+	unsigned long long zs_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
+#define ZSTAMP(i)                                                              \
+	do {                                                                   \
+		__builtin_amdgcn_sched_barrier(0);                             \
+		const unsigned long long zs_n = __builtin_amdgcn_s_memtime(); \
+		zs_acc[(i) & 7] += zs_n - zs_t;                                \
+		zs_t = zs_n;                                                   \
+		__builtin_amdgcn_sched_barrier(0);                             \
+	} while (0)
+#define ZSTAMP_FLUSH()                                                   \
+	do {                                                             \
+		if ((threadIdx.x & 63) == 0)                             \
+			for (int zs_i = 0; zs_i < 8; zs_i++)             \
+				atomicAdd(&g_zstamp[zs_i], zs_acc[zs_i]); \
+	} while (0)
+#else
+#define ZSTAMP_DECL
+#define ZSTAMP(i)
+#define ZSTAMP_FLUSH()
+#endif
+
 // (four reads = four waves per workgroup: a CU holds twice as many waves that way)
 // (room for 4 waves per SIMD: 128 instead of 147 registers, 0.71 -> 0.69 ms; 5: slower)
 #ifndef ZSWALK_WAVES
@@ -1027,15 +1068,29 @@ __global__ __launch_bounds__(256, ZSWALK_WAVES) void k_zs_walk(DecodeArgs a, ZsB
 	const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (r >= a.nreads)
 		return;
+#ifdef HUF_STAMPS
+	const unsigned long long wt0 = __builtin_amdgcn_s_memtime();
+#endif
 	const uint32_t cap_n = a.nsamp[r];
 	const uint64_t cap = zs_content_max(cap_n, z.kdiv); // what zs_slot() leaves room for
 	DevSink sink{ z, a.in_off[r], z.zoff[r], r, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, false, 0, 0 };
 	sink.lit_abs = z.lit_base + z.zoff[r];
+#ifdef HUF_STAMPS
+	sink.st_t = wt0;
+#endif
 	int64_t L = zs::walk_frame(a.in + a.in_off[r], a.in_len[r], cap, sink, work);
 	sink.close_unit();
 	sink.close_copies();
 	if (L >= 0 && sink.overflow)
 		L = zs::W_HOST;
+#ifdef HUF_STAMPS
+	sink.stamp(6); // the end of the walk
+	if ((threadIdx.x & 63) == 0 && r < 8192)
+		g_walk_ticks[r] = (uint32_t) (__builtin_amdgcn_s_memtime() - wt0);
+	if ((threadIdx.x & 63) == 0)
+		for (int i = 0; i < 8; i++)
+			atomicAdd(&g_wstamp[i], sink.st_acc[i]);
+#endif
 	if (threadIdx.x & 63)
 		return;
 	ZsRead rd;
@@ -1089,32 +1144,6 @@ __global__ __launch_bounds__(256) void k_zs_copy(DecodeArgs a, ZsBufs z)
 		copy_piece(a, z, z.dcopy[i]);
 }
 
-#ifdef HUF_STAMPS
-// diagnostic build only (tools/zsstamps.py): s_memtime differences of a wave of k_zs_hdecode, summed per phase
-__device__ unsigned long long g_zstamp[8];
-#define ZSTAMP_DECL                                             \
-	unsigned long long zs_t = __builtin_amdgcn_s_memtime(); \
-	unsigned long long zs_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
-#define ZSTAMP(i)                                                              \
-	do {                                                                   \
-		__builtin_amdgcn_sched_barrier(0);                             \
-		const unsigned long long zs_n = __builtin_amdgcn_s_memtime(); \
-		zs_acc[(i) & 7] += zs_n - zs_t;                                \
-		zs_t = zs_n;                                                   \
-		__builtin_amdgcn_sched_barrier(0);                             \
-	} while (0)
-#define ZSTAMP_FLUSH()                                                   \
-	do {                                                             \
-		if ((threadIdx.x & 63) == 0)                             \
-			for (int zs_i = 0; zs_i < 8; zs_i++)             \
-				atomicAdd(&g_zstamp[zs_i], zs_acc[zs_i]); \
-	} while (0)
-#else
-#define ZSTAMP_DECL
-#define ZSTAMP(i)
-#define ZSTAMP_FLUSH()
-#endif
-
 constexpr uint32_t HD_SYMS = 64; // bytes decoded per round (32: 2.06 ms, 64: 1.92 ms)
 constexpr uint32_t HD_IN = 96;   // stream bytes staged per round: 64 codes of at most 11 bits, 11 more, whole bytes
 // one wave per PAIR of units (a unit = up to ZU blocks of one read = 32 streams; the mean read has
@@ -1126,7 +1155,6 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	__shared__ uint16_t dt2[2][2048];
 	__shared__ uint32_t sin[64][HD_IN / 4 + 3];   // odd stride (27): a lane's slot starts in its own bank; one dword
 	                                              // of zeros in front of the bytes, one behind (a pair is read)
-	__shared__ uint32_t sout[64][HD_SYMS / 4 + 1];
 	const uint32_t total = z.dctl->nunits < z.cap_units ? z.dctl->nunits : z.cap_units;
 	if (2 * blockIdx.x >= total)
 		return;
@@ -1245,7 +1273,6 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	if (active)
 		bp = (int32_t) (8 * (len - 1)) + (31 - __builtin_clz((uint32_t) p[len - 1]));
 	uint32_t *myin = sin[lane];
-	uint32_t *myout = sout[lane];
 	myin[0] = 0; // stream byte base + j of a round sits at slot byte 4 + j: bits "below the stream" read as zeros
 	const uint32_t tsh = 11 - tl;
 	ZSTAMP(1); // stream headers
@@ -1293,13 +1320,12 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 			}
 		}
 		ZSTAMP(2); // staging
-		uint32_t acc = 0;
 		const int32_t c0 = 32 - 11 - 8 * base; // slot bit of stream bit b: b + 32 - 8 base
 		// the two dwords around slot bit bp + c0 stay in registers; the dword below them is fetched while
 		// the table look-up is in flight (a step moves down by at most 11 bits: at most one dword)
 		uint32_t w0 = (uint32_t) (bp + c0) >> 5;
 		uint32_t lo = myin[w0], hi = myin[w0 + 1];
-		for (uint32_t i = 0; i < cnt; i++) {
+		auto step = [&]() -> uint32_t { // one code: its byte
 			const uint32_t below = myin[w0 ? w0 - 1 : 0];
 			const uint32_t v11 = __builtin_amdgcn_alignbit(hi, lo, (uint32_t) (bp + c0)) & 0x7FFu; // shift = low 5 bits
 			const uint32_t e = dt[v11 >> tsh];
@@ -1314,39 +1340,42 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 				lo = below;
 			}
 			w0 = wn;
-			acc |= (e & 0xFFu) << (8 * (i & 3));
-			if ((i & 3) == 3) {
-				myout[i >> 2] = acc;
-				acc = 0;
-			}
-		}
-		if (cnt & 3)
-			myout[cnt >> 2] = acc;
-		ZSTAMP(3); // decode
-		// ---- the round's bytes out: four lanes share a stream's 64 bytes, 16 each, so that a
-		// store instruction writes 16 runs of 64 bytes instead of 64 scattered dwords (which cost
-		// as much as all the decoding: measured)
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		{
-			const uint64_t optr = (uint64_t) (uintptr_t) (out + done);
-			constexpr int PS = HD_SYMS / 16; // lanes per stream
+			return e & 0xFFu;
+		};
+		// ---- sixteen codes at a time, their bytes stored from registers: 16 bytes per lane and store.  (Through an
+		// LDS slot per lane and stores shared by four lanes - 64-byte runs - the slots were 4.3 KB of a wave's 19 KB:
+		// 8 waves per CU; scattered DWORD stores had cost as much as the decoding.)
+		uint8_t *o = out + done;
+		if (!__any(go && cnt != HD_SYMS)) { // every stream of the wave that is still running has a whole round
+			if (go) {
+				for (uint32_t g = 0; g < HD_SYMS / 16; g++) {
+					uint32_t a4[4] = { 0, 0, 0, 0 };
 #pragma unroll
-			for (int c = 0; c < PS; c++) {
-				const int o = (64 / PS) * c + lane / PS, part = lane % PS;
-				const uint32_t ocnt = (uint32_t) __shfl((int) cnt, o);
-				const uint64_t op = ((uint64_t) (uint32_t) __shfl((int) (optr >> 32), o) << 32) | (uint32_t) __shfl((int) optr, o);
-				if (ocnt == HD_SYMS) {
-					const uint32_t *row = sout[o] + 4 * part;
-					const uint4 v = make_uint4(row[0], row[1], row[2], row[3]);
-					__builtin_memcpy((uint8_t *) (uintptr_t) op + 16 * part, &v, 16);
+					for (int j = 0; j < 16; j++)
+						a4[j >> 2] |= step() << (8 * (j & 3));
+					const uint4 v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
+					__builtin_memcpy(o + 16 * g, &v, 16);
 				}
 			}
-			if (cnt && cnt < HD_SYMS) // the last, short round of a stream
-				for (uint32_t e = 0; e < cnt; e++)
-					out[done + e] = (uint8_t) (myout[e >> 2] >> (8 * (e & 3)));
+		} else { // a stream's last, short round
+			for (uint32_t g = 0; g < HD_SYMS / 16; g++) {
+				uint32_t a4[4] = { 0, 0, 0, 0 };
+#pragma unroll
+				for (int j = 0; j < 16; j++)
+					if (16 * g + j < cnt)
+						a4[j >> 2] |= step() << (8 * (j & 3));
+				if (cnt >= 16 * g + 16) {
+					const uint4 v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
+					__builtin_memcpy(o + 16 * g, &v, 16);
+				} else if (cnt > 16 * g) {
+#pragma unroll
+					for (int j = 0; j < 16; j++)
+						if (16 * g + j < cnt)
+							o[16 * g + j] = (uint8_t) (a4[j >> 2] >> (8 * (j & 3)));
+				}
+			}
 		}
+		ZSTAMP(3); // decode, stores
 		__builtin_amdgcn_wave_barrier();
 		ZSTAMP(4); // stores
 	}
@@ -1508,6 +1537,14 @@ void launch_zstd_decode_streams(const DecodeArgs &a, const ZsBufs &z, hipStream_
 } // namespace ph
 
 #ifdef HUF_STAMPS
+extern "C" int press_hip_zs_walk_stamps(unsigned long long *dst)
+{
+	return hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(dst, HIP_SYMBOL(ph::g_wstamp), 64) == hipSuccess ? 0 : -1;
+}
+extern "C" int press_hip_zs_walk_ticks(uint32_t *dst)
+{
+	return hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(dst, HIP_SYMBOL(ph::g_walk_ticks), 8192 * 4) == hipSuccess ? 0 : -1;
+}
 extern "C" int press_hip_zs_stamps(unsigned long long *dst)
 {
 	unsigned long long z[8] = { 0 };

@@ -43,12 +43,17 @@ struct Table {
 // scratch of build_table (LDS on the device)
 struct Work {
 	uint32_t w[512];     // node weights
-	uint16_t parent[512];
-	uint8_t depth[512];
-	uint8_t weight[256];
+	uint16_t parent[512]; // (the device keeps the occurrence counts here until the leaves' weights are in w: 8 reads' scratch
+	                      // per CU instead of 6 - all 8192 reads of a batch in one round)
+	union {               // the depths are done with when the weights are written
+		uint8_t depth[512];
+		struct {
+			uint8_t weight[256];
+			uint16_t state_tab[64];
+			uint8_t spread[64];
+		};
+	};
 	uint16_t cum[16];
-	uint16_t state_tab[64];
-	uint8_t spread[64];
 	// small tables (kept here rather than in locals: indexed at run time, and a GPU lane's
 	// locals of that kind live in scratch memory)
 	uint32_t bl[MAXLEN + 2], wc[13], norm[13], dfs[13], dnb[13];
@@ -513,8 +518,58 @@ ZS_FN uint32_t back_read(BackBits &b, uint32_t n) // the n <= 16 bits below pos,
 	return v;
 }
 
+// ---- the same reader with the stream's next bits in a register (the FSE state machines are chains of "table entry ->
+// that many bits -> next state": with three byte loads per read in that chain the tree description of one frame took a
+// device wave 0.3 M cycles).  acc holds the next `have` bits in its low bits, the one read first on top; bytes are taken
+// in BEHIND a read, so their loads run next to the table look-up of the following step.
+struct BackWin {
+	const uint8_t *p;
+	int32_t pos;   // bits left below the mark; negative: read past the start
+	int32_t nextb; // the next byte to take in (descending); < 0: none left
+	uint64_t acc;
+	uint32_t have;
+};
+ZS_FN void backwin_fill(BackWin &b)
+{
+	while (b.have <= 56 && b.nextb >= 0) {
+		b.acc = (b.acc << 8) | b.p[b.nextb--];
+		b.have += 8;
+	}
+}
+ZS_FN bool backwin_init(BackWin &b, const uint8_t *p, uint32_t len) // len < 2^28
+{
+	if (!len || !p[len - 1])
+		return false;
+	const uint32_t h = highbit(p[len - 1]);
+	b.p = p;
+	b.pos = (int32_t) (8 * (len - 1) + h);
+	b.acc = p[len - 1] & ((1u << h) - 1u);
+	b.have = h;
+	b.nextb = (int32_t) len - 2;
+	backwin_fill(b);
+	return true;
+}
+ZS_FN uint32_t backwin_read(BackWin &b, uint32_t n) // as back_read: n <= 16, zeros below bit 0
+{
+	if (!n)
+		return 0;
+	const uint32_t mask = (1u << n) - 1u;
+	uint32_t v;
+	if (b.have >= n) {
+		b.have -= n;
+		v = (uint32_t) (b.acc >> b.have) & mask;
+	} else { // (backwin_fill keeps more than 56 bits while bytes are left: the stream ends here)
+		v = (uint32_t) (b.acc << (n - b.have)) & mask;
+		b.have = 0;
+		b.acc = 0;
+	}
+	b.pos -= (int32_t) n;
+	backwin_fill(b);
+	return v;
+}
+
 // scratch of the reading side (LDS on the device, where every lane of a wave runs the same walk)
-constexpr uint32_t WIN = 32; // frame bytes fetched at a time by walk_frame
+constexpr uint32_t WIN = 128; // frame bytes fetched at a time by walk_frame (a run of 4-byte RLE blocks in one fetch)
 // FSE decoding table of one of the three sequence symbol types (RFC 8878 3.1.1.3.2.1): at most 9 bits
 struct SeqTab {
 	uint8_t sym[512], nb[512];
@@ -526,8 +581,9 @@ struct ReadWork {
 	uint8_t win[WIN];
 	uint8_t w[256];
 	uint8_t desc[DESC_MAX + 4];
-	uint8_t dsym[64], dnb[64];
-	uint16_t dnew[64], next[16];
+	uint8_t dsym[64];
+	uint32_t dtab[64]; // FSE decoding table of the weights: value | bits << 8 | (next state's base) << 16
+	uint16_t next[16];
 	int norm[16];
 	// sequences
 	SeqTab st[3];      // literal lengths, offsets, match lengths
@@ -540,8 +596,9 @@ struct ReadWork {
 ZS_FN uint32_t fse_read_weights(const uint8_t *src, uint32_t len, uint8_t *w, uint32_t max_out, ReadWork &k)
 {
 	int *norm = k.norm;
-	uint8_t *dsym = k.dsym, *dnb = k.dnb;
-	uint16_t *dnew = k.dnew, *next = k.next;
+	uint8_t *dsym = k.dsym;
+	uint32_t *dtab = k.dtab;
+	uint16_t *next = k.next;
 	FwdBits f{ src, len, 0 };
 	const uint32_t tl = fwd_peek(f, 4) + 5;
 	f.pos += 4;
@@ -624,26 +681,27 @@ ZS_FN uint32_t fse_read_weights(const uint8_t *src, uint32_t len, uint8_t *w, ui
 		const uint32_t s = dsym[u];
 		const uint32_t nx = next[s]++;
 		const uint32_t nb = tl - highbit(nx);
-		dnb[u] = (uint8_t) nb;
-		dnew[u] = (uint16_t) ((nx << nb) - (uint32_t) ts);
+		dtab[u] = s | (nb << 8) | (((nx << nb) - (uint32_t) ts) << 16);
 	}
 	// ---- two interleaved states; whoever reads past the start ends it, the other adds its symbol
-	BackBits b;
-	if (len <= hbytes || !back_init(b, src + hbytes, len - hbytes))
+	BackWin b;
+	if (len <= hbytes || !backwin_init(b, src + hbytes, len - hbytes))
 		return 0;
-	uint32_t st[2];
-	st[0] = back_read(b, tl);
-	st[1] = back_read(b, tl);
+	uint32_t e[2]; // the states' table entries
+	e[0] = backwin_read(b, tl);
+	e[1] = backwin_read(b, tl);
 	if (b.pos < 0)
 		return 0;
+	e[0] = dtab[e[0]];
+	e[1] = dtab[e[1]];
 	uint32_t out = 0;
 	for (int q = 0;; q ^= 1) {
 		if (out + 2 > max_out)
 			return 0;
-		w[out++] = dsym[st[q]];
-		st[q] = dnew[st[q]] + back_read(b, dnb[st[q]]);
+		w[out++] = (uint8_t) e[q];
+		e[q] = dtab[(e[q] >> 16) + backwin_read(b, (e[q] >> 8) & 0xFFu)];
 		if (b.pos < 0) {
-			w[out++] = dsym[st[q ^ 1]];
+			w[out++] = (uint8_t) e[q ^ 1];
 			break;
 		}
 	}
@@ -934,6 +992,11 @@ ZS_FN uint32_t seq_table(int which, uint32_t mode, const uint8_t *p, uint32_t av
 // Returns the content size, or W_BAD (malformed) / W_HOST (valid zstd this reader leaves to
 // libzstd: dictionaries, 12-bit tables, several frames, more sequences than the sink takes).
 constexpr int64_t W_BAD = -1, W_HOST = -2;
+#if defined(HUF_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define ZS_STAMP(sink, i) (sink).stamp(i) // diagnostic build: where a wave of k_zs_walk spends its time
+#else
+#define ZS_STAMP(sink, i) ((void) 0)
+#endif
 
 // Frame bytes come through a window of WIN bytes that the sink fills (sink.fetch(dst, src, n):
 // on the device a wave's lanes share the loads).  The walk touches a few bytes per block - the
@@ -951,7 +1014,9 @@ template <class Sink> struct FrameSrc {
 			// (a backward reader - the sequences' bit stream - gets the bytes in front of i as well)
 			base = valid && i < base ? (i >= WIN - 1 ? i - (WIN - 1) : 0) : i;
 			valid = true;
+			ZS_STAMP(sink, 7);
 			sink.fetch(k.win, f + base, len - base < WIN ? (uint32_t) (len - base) : WIN);
+			ZS_STAMP(sink, 0); // window fetches
 		}
 		return k.win[i - base];
 	}
@@ -996,13 +1061,17 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, 
 		if (type == 0) {
 			if (at + bs > len || dst + bs > cap)
 				return W_BAD;
+			ZS_STAMP(sink, 7);
 			sink.copy(at, dst, bs, false);
+			ZS_STAMP(sink, 1); // raw / RLE pieces queued
 			at += bs;
 			dst += bs;
 		} else if (type == 1) {
 			if (at + 1 > len || dst + bs > cap)
 				return W_BAD;
+			ZS_STAMP(sink, 7);
 			sink.fill(at, dst, bs, false);
+			ZS_STAMP(sink, 1);
 			at += 1;
 			dst += bs;
 		} else {
@@ -1069,13 +1138,17 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, 
 					uint8_t *w = k.w;
 					uint32_t tl;
 					const uint32_t dn = cs < (uint32_t) DESC_MAX ? cs : (uint32_t) DESC_MAX;
+					ZS_STAMP(sink, 7);
 					sink.fetch(k.desc, fp + src, dn);
+					ZS_STAMP(sink, 2); // the tree description fetched
 					const uint32_t used = read_tree(k.desc, dn, w, &tl, k, sink);
+					ZS_STAMP(sink, 3); // ... read
 					if (used == 0)
 						return W_BAD;
 					if (used == 0xFFFFFFFFu)
 						return W_HOST;
 					const int64_t e = sink.tree(w, tl);
+					ZS_STAMP(sink, 4); // ... stored
 					if (e)
 						return e;
 					src += used;
@@ -1088,7 +1161,9 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, 
 				if (four ? (cs < 10 || R < 4) : cs < 1)
 					return W_BAD;
 				if (R) {
+					ZS_STAMP(sink, 7);
 					const int64_t e = sink.huf(src, cs, ldst, R, four, seqs);
+					ZS_STAMP(sink, 5); // Huffman blocks queued
 					if (e)
 						return e;
 				}

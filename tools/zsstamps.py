@@ -19,3 +19,27 @@ names = ["tables", "stream headers", "staging (loads -> LDS)", "decode loop", "s
 tot = float(sum(int(x) for x in buf))
 for i, n in enumerate(names):
     print("%-26s %14d ticks  %5.1f %%" % (n, int(buf[i]), 100.0 * int(buf[i]) / tot))
+
+# k_zs_walk: ticks of each read's wave against the read's length
+wt = np.zeros(8192, dtype=np.uint32)
+lib.press_hip_zs_walk_ticks.argtypes = [ctypes.c_void_p]
+assert lib.press_hip_zs_walk_ticks(wt.ctypes.data) == 0
+from honours_amd import synth
+n, _ = synth.read_lengths(20261004, 0, 8192)
+blocks = (n + 16383) // 16384
+print("walk: ticks per read  min %d  median %d  p90 %d  max %d" % (wt.min(), np.median(wt), np.percentile(wt, 90), wt.max()))
+A = np.vstack([np.ones(8192), blocks]).T
+coef = np.linalg.lstsq(A, wt.astype(np.float64), rcond=None)[0]
+print("walk: ticks ~ %.0f + %.0f per data block (least squares); longest read: %d blocks, %d ticks" % (coef[0], coef[1], blocks.max(), wt[np.argmax(blocks)]))
+for lo, hi in ((1, 2), (3, 5), (6, 10), (11, 20), (21, 40), (41, 200)):
+    m = (blocks >= lo) & (blocks <= hi)
+    print("  blocks %3d..%3d: reads %5d  mean ticks %9.0f" % (lo, hi, m.sum(), wt[m].mean() if m.any() else 0))
+
+ws = np.zeros(8, dtype=np.uint64)
+lib.press_hip_zs_walk_stamps.argtypes = [ctypes.c_void_p]
+assert lib.press_hip_zs_walk_stamps(ws.ctypes.data) == 0
+wn = ["window fetches", "raw / RLE pieces queued", "tree description fetched", "tree description read", "tree stored",
+      "Huffman blocks queued", "end of the walk", "the walk's own code"]
+tot = float(ws.sum())
+for i, nme in enumerate(wn):
+    print("walk %-28s %14d ticks  %5.1f %%" % (nme, int(ws[i]), 100.0 * int(ws[i]) / tot))
