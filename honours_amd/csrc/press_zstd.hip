@@ -1144,15 +1144,22 @@ __global__ __launch_bounds__(256) void k_zs_copy(DecodeArgs a, ZsBufs z)
 		copy_piece(a, z, z.dcopy[i]);
 }
 
-constexpr uint32_t HD_SYMS = 64; // bytes decoded per round (32: 2.06 ms, 64: 1.92 ms)
-constexpr uint32_t HD_IN = 96;   // stream bytes staged per round: 64 codes of at most 11 bits, 11 more, whole bytes
+#ifndef HD_SYMS_N
+#define HD_SYMS_N 64
+#define HD_IN_N 96
+#endif
+constexpr uint32_t HD_SYMS = HD_SYMS_N; // bytes decoded per round
+constexpr uint32_t HD_IN = HD_IN_N;     // stream bytes staged per round: HD_SYMS codes of at most 11 bits, 11 more, whole 16 bytes
+static_assert(HD_SYMS % 16 == 0 && HD_IN % 16 == 0 && 8 * HD_IN >= 11 * HD_SYMS + 11 + 7, "a round's codes are staged");
 // one wave per PAIR of units (a unit = up to ZU blocks of one read = 32 streams; the mean read has
 // 7 blocks, so whole waves per read would leave more than half of the lanes idle - and the
 // kernel is bound by the instructions per decoded byte, not by latency): two tables in LDS,
 // one lane per bit stream
 __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 {
-	__shared__ uint16_t dt2[2][2048];
+	// the two tables, always indexed by 11 stream bits (a shorter table log: every entry 2^(11 - log) times), each on a
+	// 4096-byte boundary: a look-up's LDS address is (window & 0xFFE) | base - one instruction
+	__shared__ __attribute__((aligned(4096))) uint16_t dt2[2][2048];
 	__shared__ uint32_t sin[64][HD_IN / 4 + 3];   // odd stride (27): a lane's slot starts in its own bank; one dword
 	                                              // of zeros in front of the bytes, one behind (a pair is read)
 	const uint32_t total = z.dctl->nunits < z.cap_units ? z.dctl->nunits : z.cap_units;
@@ -1204,7 +1211,7 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 			continue;
 		for (int sl = 0; sl < 64; sl++)
 			for (int i = 0; i < 4; i++) {
-				const uint32_t s0 = __shfl(st[i], sl), n0 = __shfl(nn[i], sl), x0 = __shfl(w4[i], sl);
+				const uint32_t s0 = __shfl(st[i], sl) << (11 - tl), n0 = __shfl(nn[i], sl) << (11 - tl), x0 = __shfl(w4[i], sl);
 				const uint32_t e = (uint32_t) (4 * sl + i) | ((tl + 1 - x0) << 8);
 				for (uint32_t k = lane; k < n0; k += 64)
 					dt[s0 + k] = (uint16_t) e;
@@ -1217,8 +1224,8 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	ZSTAMP(0); // tables
 	const int half = lane >> 5;
 	const uint32_t u = 2 * blockIdx.x + half;
-	const uint32_t tl = half ? tlh[1] : tlh[0];
-	const uint16_t *dt = dt2[half];
+	typedef __attribute__((address_space(3))) const uint16_t *lds_cu16p;
+	const uint32_t dtb = (uint32_t) (uintptr_t) (lds_cu16p) dt2[half]; // (a multiple of 4096)
 	ZsUnit un;
 	un.count = half ? cnth[1] : cnth[0];
 	un.read = half ? readh[1] : readh[0];
@@ -1274,7 +1281,6 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 		bp = (int32_t) (8 * (len - 1)) + (31 - __builtin_clz((uint32_t) p[len - 1]));
 	uint32_t *myin = sin[lane];
 	myin[0] = 0; // stream byte base + j of a round sits at slot byte 4 + j: bits "below the stream" read as zeros
-	const uint32_t tsh = 11 - tl;
 	ZSTAMP(1); // stream headers
 	for (uint32_t done = 0; __any(active && done < k); done += HD_SYMS) {
 		const bool go = active && done < k;
@@ -1320,21 +1326,27 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 			}
 		}
 		ZSTAMP(2); // staging
-		const int32_t c0 = 32 - 11 - 8 * base; // slot bit of stream bit b: b + 32 - 8 base
-		// the two dwords around slot bit bp + c0 stay in registers; the dword below them is fetched while
+		// sp = the slot bit ONE BELOW the eleven bits a look-up wants (stream bit b sits at slot bit b + 32 - 8 base): the
+		// window cut at sp has the table index in bits 1 .. 11 - twice the index, the entry's byte offset.  The chain
+		// from one code to the next is cut - mask/or - look-up - subtract - clamp - dword test - select: the clamp at
+		// the stream's bit 0 replaces a compare and a select, the bits are also summed next to the chain and compared
+		// with what the stream had when the round is over (1.52 -> ms).
+		const int32_t c0 = 32 - 11 - 1 - 8 * base;
+		const int32_t bp0 = bp;
+		int32_t sp = bp + c0;
+		uint32_t used = 0;
+		// the two dwords around slot bit sp stay in registers; the dword below them is fetched while
 		// the table look-up is in flight (a step moves down by at most 11 bits: at most one dword)
-		uint32_t w0 = (uint32_t) (bp + c0) >> 5;
+		uint32_t w0 = (uint32_t) sp >> 5;
 		uint32_t lo = myin[w0], hi = myin[w0 + 1];
 		auto step = [&]() -> uint32_t { // one code: its byte
 			const uint32_t below = myin[w0 ? w0 - 1 : 0];
-			const uint32_t v11 = __builtin_amdgcn_alignbit(hi, lo, (uint32_t) (bp + c0)) & 0x7FFu; // shift = low 5 bits
-			const uint32_t e = dt[v11 >> tsh];
-			bp -= (int32_t) (e >> 8);
-			if (bp < 0) { // more code bits than the stream has
-				overrun = true;
-				bp = 0;
-			}
-			const uint32_t wn = (uint32_t) (bp + c0) >> 5;
+			const uint32_t y = __builtin_amdgcn_alignbit(hi, lo, (uint32_t) sp); // shift = low 5 bits
+			const uint32_t e = *(lds_cu16p) (uintptr_t) ((y & 0xFFEu) | dtb);
+			const uint32_t nb = e >> 8;
+			used += nb;
+			sp = max(sp - (int32_t) nb, c0); // (c0: the stream's bit 0 - only a damaged stream gets there before its last code)
+			const uint32_t wn = (uint32_t) sp >> 5;
 			if (wn != w0) {
 				hi = lo;
 				lo = below;
@@ -1374,6 +1386,10 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 							o[16 * g + j] = (uint8_t) (a4[j >> 2] >> (8 * (j & 3)));
 				}
 			}
+		}
+		if (go) {
+			overrun |= used > (uint32_t) bp0; // more code bits than the stream has
+			bp = sp - c0;
 		}
 		ZSTAMP(3); // decode, stores
 		__builtin_amdgcn_wave_barrier();
