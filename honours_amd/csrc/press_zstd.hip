@@ -645,7 +645,6 @@ __global__ __launch_bounds__(256) void k_zs_encode(BatchArgs a, ZsBufs z)
 {
 	__shared__ uint32_t enc[256];       // code | len << 16
 	__shared__ uint32_t stg_all[4][ZSTG];
-	__shared__ __attribute__((aligned(16))) uint8_t lit[4][4096]; // (padding the lanes' 64-byte runs apart: measured, no gain)
 	const uint32_t b = blockIdx.x;
 	if (b >= *z.nblocks)
 		return;
@@ -670,17 +669,29 @@ __global__ __launch_bounds__(256) void k_zs_encode(BatchArgs a, ZsBufs z)
 		stg[i] = 0;
 	const uint32_t seg = (u.R + 3) / 4;
 	const uint32_t k = q < 3 ? seg : u.R - 3 * seg;
-	{ // the stream's bytes into LDS, 16 per lane and step
-		const uint8_t *s = u.data + (uint64_t) q * seg;
-		for (uint32_t i0 = lane * 16; i0 < k; i0 += 1024) {
-			if (i0 + 16 <= k) {
-				uint4 v;
-				__builtin_memcpy(&v, s + i0, 16);
-				*reinterpret_cast<uint4 *>(&lit[q][i0]) = v;
-			} else {
-				for (uint32_t e = i0; e < k; e++)
-					lit[q][e] = s[e];
+	// ---- a lane's run of the stream: 64 bytes (the lanes behind a short stream's end have none), loaded straight into
+	// registers.  (Through LDS, a lane's 64-byte run 64 bytes from its neighbour's: every dword read of the runs was a
+	// 32-way bank conflict - two thirds of the kernel's LDS cycles - and the 16 KB cost a third of the resident waves.)
+	const uint32_t lo = 64u * lane < k ? 64u * lane : k, hi = lo + 64 < k ? lo + 64 : k;
+	const uint32_t nmine = hi - lo;
+	uint32_t run[16];
+	{
+		const uint8_t *s = u.data + (uint64_t) q * seg + lo;
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			uint4 v = make_uint4(0, 0, 0, 0);
+			if (16u * j + 16u <= nmine) {
+				__builtin_memcpy(&v, s + 16 * j, 16);
+			} else if (16u * j < nmine) { // the stream's last, ragged 16 bytes (one lane)
+				uint32_t x[4] = { 0, 0, 0, 0 };
+				for (uint32_t e = 16u * j; e < nmine; e++)
+					x[(e >> 2) & 3] |= (uint32_t) s[e] << (8 * (e & 3));
+				v = make_uint4(x[0], x[1], x[2], x[3]);
 			}
+			run[4 * j] = v.x;
+			run[4 * j + 1] = v.y;
+			run[4 * j + 2] = v.z;
+			run[4 * j + 3] = v.w;
 		}
 	}
 	__syncthreads();
@@ -706,22 +717,25 @@ __global__ __launch_bounds__(256) void k_zs_encode(BatchArgs a, ZsBufs z)
 			blk[8 + i] = t->desc[i];
 	// ---- the stream: the bytes back to front, the first byte's code on top, then the end mark.
 	// A lane packs its contiguous run of codes in a register and ORs whole dwords into LDS.
-	const uint32_t c = (k + 63) / 64;
-	const uint32_t lo = lane * c < k ? lane * c : k, hi = lo + c < k ? lo + c : k;
-	// (a full stream gives every lane 64 bytes: four at a time, so that the look-ups of four
-	// codes are in flight together instead of one LDS round trip after the other)
-	const bool full = c == 64 && k == 4096;
+	// (Four bytes at a time, so that the look-ups of four codes are in flight together.)
+	const bool whole = !__any(nmine != 0 && nmine != 64); // no lane of the wave with a ragged run
 	uint32_t mybits = 0;
-	if (full) {
-#pragma unroll 4
-		for (uint32_t w4 = 0; w4 < 16; w4++) {
-			const uint32_t four = *reinterpret_cast<const uint32_t *>(&lit[q][lo + 4 * w4]);
-			mybits += (enc[four & 0xFFu] >> 16) + (enc[(four >> 8) & 0xFFu] >> 16) + (enc[(four >> 16) & 0xFFu] >> 16) +
-				  (enc[four >> 24] >> 16);
+	if (whole) {
+		if (nmine) {
+#pragma unroll
+			for (int w4 = 0; w4 < 16; w4++) {
+				const uint32_t four = run[w4];
+				mybits += (enc[four & 0xFFu] >> 16) + (enc[(four >> 8) & 0xFFu] >> 16) + (enc[(four >> 16) & 0xFFu] >> 16) +
+					  (enc[four >> 24] >> 16);
+			}
 		}
 	} else {
-		for (uint32_t i = lo; i < hi; i++)
-			mybits += enc[lit[q][i]] >> 16;
+#pragma unroll
+		for (int w4 = 0; w4 < 16; w4++)
+#pragma unroll
+			for (int e = 0; e < 4; e++)
+				if ((uint32_t) (4 * w4 + e) < nmine)
+					mybits += enc[(run[w4] >> (8 * e)) & 0xFFu] >> 16;
 	}
 	const uint32_t inc = wave_incl32(mybits, lane);
 	const uint32_t totalb = __shfl(inc, 63);
@@ -738,20 +752,26 @@ __global__ __launch_bounds__(256) void k_zs_encode(BatchArgs a, ZsBufs z)
 				nb -= 32;
 			}
 		};
-		if (full) {
-#pragma unroll 2
-			for (int w4 = 15; w4 >= 0; w4--) {
-				const uint32_t four = *reinterpret_cast<const uint32_t *>(&lit[q][lo + 4 * w4]);
-				const uint32_t e3 = enc[four >> 24], e2 = enc[(four >> 16) & 0xFFu], e1 = enc[(four >> 8) & 0xFFu],
-					       e0 = enc[four & 0xFFu];
-				put(e3);
-				put(e2);
-				put(e1);
-				put(e0);
+		if (whole) {
+			if (nmine) {
+#pragma unroll
+				for (int w4 = 15; w4 >= 0; w4--) {
+					const uint32_t four = run[w4];
+					const uint32_t e3 = enc[four >> 24], e2 = enc[(four >> 16) & 0xFFu], e1 = enc[(four >> 8) & 0xFFu],
+						       e0 = enc[four & 0xFFu];
+					put(e3);
+					put(e2);
+					put(e1);
+					put(e0);
+				}
 			}
 		} else {
-			for (uint32_t i = hi; i-- > lo;)
-				put(enc[lit[q][i]]);
+#pragma unroll
+			for (int w4 = 15; w4 >= 0; w4--)
+#pragma unroll
+				for (int e = 3; e >= 0; e--)
+					if ((uint32_t) (4 * w4 + e) < nmine)
+						put(enc[(run[w4] >> (8 * e)) & 0xFFu]);
 		}
 		if (lane == 0) { // the end mark sits on top of the first byte's code
 			acc |= 1ull << nb;

@@ -25,7 +25,11 @@
 
 namespace zs {
 
-constexpr int MAXLEN = 11;          // longest code (zstd's encoder: HUF_TABLELOG_DEFAULT)
+#ifndef ZS_MAXLEN
+#define ZS_MAXLEN 11
+#endif
+constexpr int MAXLEN = ZS_MAXLEN;   // longest code the writer makes (zstd's encoder: HUF_TABLELOG_DEFAULT = 11)
+constexpr int READ_MAXLEN = 11;     // longest code the device reader takes (12, the format's limit: left to libzstd)
 constexpr int DESC_MAX = 132;       // header byte + at most 127 bytes (FSE) / 64 bytes (direct)
 constexpr uint32_t BLOCK_LITS = 16384; // data bytes per Huffman block
 constexpr uint32_t MIN_HUF_LITS = 64;  // shorter tails are stored raw
@@ -763,7 +767,7 @@ ZS_FN uint32_t read_tree(const uint8_t *p, uint32_t avail, uint8_t *w, uint32_t 
 		w[i] = i == n ? (uint8_t) lastw : 0;
 	par.sync();
 	*table_log = tl;
-	return tl > (uint32_t) MAXLEN ? 0xFFFFFFFFu : used;
+	return tl > (uint32_t) READ_MAXLEN ? 0xFFFFFFFFu : used;
 }
 
 // ---- sequences (RFC 8878 3.1.1.3.2): three FSE-coded symbol streams interleaved in one backward bit stream
