@@ -307,6 +307,7 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 	__shared__ uint32_t s_wtot[4];
 	__shared__ uint64_t s_excl;
 	__shared__ uint32_t s_hist[HIST ? 16 : 1][256];
+	__shared__ uint32_t s_knz[4];
 	uint32_t *myhist = s_hist[HIST ? 4 * (threadIdx.x >> 6) + (threadIdx.x & 3) : 0];
 	if (HIST)
 		for (int i = 0; i < 16; i++)
@@ -334,6 +335,8 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 			(void) lookback(a.gran, t, d.j, 0, last);
 			if (last && threadIdx.x == 0)
 				a.out_len[d.read] = CFAIL64;
+			if (HIST && threadIdx.x == 0)
+				a.zkcnt[t] = 0;
 		}
 		__syncthreads(); // every wave has read s_ticket before thread 0 overwrites it
 		continue;
@@ -453,6 +456,7 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 
 	// ---- phase 2: keys and data
 	uint8_t *data = out + klen;
+	uint32_t knz = 0; // HIST: key bytes of this wave's quarter that are not zero (uniform)
 #pragma unroll
 	for (int k = 0; k < CK; k++) {
 		const uint32_t i0 = ws + k * SUB + lane * 8;
@@ -515,6 +519,8 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 		if (nv) {
 			if (!KEY2) {
 				out[i0 >> 3] = (uint8_t) key;
+				if (HIST)
+					knz += (uint32_t) __popcll(__ballot(key != 0));
 			} else {
 				uint32_t k0 = 0, k1 = 0;
 #pragma unroll
@@ -525,6 +531,8 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 				out[i0 >> 2] = (uint8_t) k0;
 				if (nv > 4)
 					out[(i0 >> 2) + 1] = (uint8_t) k1;
+				if (HIST)
+					knz += (uint32_t) (__popcll(__ballot(k0 != 0)) + __popcll(__ballot(nv > 4 && k1 != 0)));
 			}
 			if (HIST) {
 #pragma unroll
@@ -562,7 +570,11 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 	}
 	if (HIST) { // the chunk's counts to its read's; a thread clears what it has read (the next chunk counts behind
 		    // three barriers)
+		if (lane == 0)
+			s_knz[w] = knz;
 		__syncthreads();
+		if (threadIdx.x == 0)
+			a.zkcnt[t] = s_knz[0] + s_knz[1] + s_knz[2] + s_knz[3];
 		uint32_t c = 0;
 		for (int i = 0; i < 16; i++) {
 			c += s_hist[i][threadIdx.x];

@@ -838,7 +838,8 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 	sv.out_off = z.kdiv ? z.zoff4 : z.zoff;
 	sv.out_len = z.zlen;
 	(void) hipMemsetAsync(z.hist, 0, (size_t) a.nreads * 1024, s);
-	sv.zhist = z.kdiv ? z.hist : nullptr; // svb: the data bytes are counted where they are made
+	sv.zhist = z.kdiv ? z.hist : nullptr; // svb: the data bytes - and the key bytes that are not zero - are counted where they are made
+	sv.zkcnt = z.kcnt;
 	ktime_mute(true);
 	if (z.kdiv)
 		launch_svb_encode_chunked(sv, z.kdiv == 4, true, s);
@@ -851,7 +852,8 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 			   z.blk_read);
 	if (!z.kdiv) // (the exception-split stream: counted from ztmp)
 		hipLaunchKernelGGL(k_zs_hist, dim3(z.max_blocks), dim3(256), 0, s, z);
-	hipLaunchKernelGGL(k_zs_keycount, dim3(a.max_chunks), dim3(256), 0, s, a, z);
+	if (!z.kdiv)
+		hipLaunchKernelGGL(k_zs_keycount, dim3(a.max_chunks), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_table, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_keylist, dim3(a.max_chunks), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_bits, dim3(z.max_blocks), dim3(256), 0, s, z);
