@@ -458,7 +458,7 @@ void zs_bufs(ZsBufs &z, uint64_t total_samples, uint32_t nreads, int method = PR
 	z.zn = (uint32_t *) g.zn.p;
 	// what a batch of this library's frames needs, with room for others; a frame that does not
 	// fit (tiny blocks, thousands of trees) goes to libzstd on the host
-	z.cap_copy = z.max_blocks + (uint32_t) (total_samples / 256) + 16 * nreads + 64;
+	z.cap_copy = z.max_blocks + (uint32_t) (total_samples / 256) + 32 * nreads + 64; // (16 per read are the read's own: ZCOPY_OWN)
 	z.cap_units = z.max_blocks / 8 + 2 * nreads + 64;
 	z.cap_trees = 4 * nreads + 64;
 	// frames with sequences (libzstd's own): their literals in the second half of ztmp
@@ -489,7 +489,7 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 		    g.zdseq.reserve((size_t) z.cap_seq * sizeof(ZsSeq)) || g.zdxblk.reserve((size_t) z.cap_xblk * sizeof(ZsXBlk)) ||
 		    g.zdcopy.reserve((size_t) z.cap_copy * sizeof(ZsCopy)) || g.zdhuf.reserve((size_t) z.cap_units * 8 * sizeof(ZsHuf)) ||
 		    g.zdunit.reserve((size_t) z.cap_units * sizeof(ZsUnit)) || g.zdtree.reserve((size_t) z.cap_trees * sizeof(ZsTree)) ||
-		    g.zdctl.reserve(64))
+		    g.zdctl.reserve(sizeof(ZsDCtl)))
 			return PRESS_HIP_EHIP;
 	}
 	if (is_zs(method) && !decode) {
@@ -1011,11 +1011,11 @@ static int launch_press(int method, const BatchArgs &a, hipStream_t s)
 // synchronisation per batch; a batch of this library's own frames has none of them.
 static int zs_host_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t s)
 {
-	ZsDCtl c;
-	HIPCHK(hipMemcpyAsync(&c, z.dctl, sizeof c, hipMemcpyDeviceToHost, s));
+	uint32_t nhost = 0;
+	HIPCHK(hipMemcpyAsync(&nhost, &z.dctl->nhost, sizeof nhost, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
-	g.zs_nhost = c.nhost;
-	if (!c.nhost || !zstd_open())
+	g.zs_nhost = nhost;
+	if (!nhost || !zstd_open())
 		return 0; // without libzstd those reads fail
 	const uint32_t nr = a.nreads;
 	std::vector<ZsRead> rd(nr);

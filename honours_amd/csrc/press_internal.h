@@ -232,9 +232,14 @@ struct ZsXBlk {              // a block with sequences, in the order of its fram
 	uint32_t tail;       // literals behind the last match
 	uint32_t next;       // the frame's next such block + 1, 0: none
 };
-struct ZsDCtl {
-	uint32_t ncopy, nunits, ntrees, nhost;
-	uint32_t nseq, nxblk, pad[2];
+struct ZsDCtl { // every counter on a 4-KB page of its own: they are bumped by all waves of k_zs_walk with returning atomics,
+                // which are carried out one after the other per address - and on one cache line, all of them together
+	uint32_t ncopy, pad0[1023];
+	uint32_t nunits, pad1[1023];
+	uint32_t ntrees, pad2[1023]; // trees beyond a read's first (that one is slot r of the tree list)
+	uint32_t nseq, pad3[1023];
+	uint32_t nxblk, pad4[1023];
+	uint32_t nhost, pad5[1023];
 };
 struct ZsBufs {
 	uint8_t *ztmp;        // the svb-zd streams between the two stages: [u32 n][keys][data] of read r at zoff[r]

@@ -19,6 +19,7 @@
 
 #include "press_internal.h"
 #include "zs_table.h"
+#include <type_traits>
 
 namespace ph {
 
@@ -877,6 +878,8 @@ namespace {
 // Every lane of the wave runs the same walk on the same bytes (uniform control flow, no
 // divergence between reads); lane 0 writes what is found.
 constexpr uint32_t ZU = 8; // Huffman blocks per unit (32 streams: half a wave)
+constexpr uint32_t ZCOPY_OWN = 16; // slots of the copy list every read owns (the count, the key blocks of one of this library's
+                                   // frames: no counter, which all waves of the walk would bump one after the other)
 struct DevSink {
 	const ZsBufs &z;
 	uint64_t in_base, out_base; // arena offset of the frame, ztmp offset of the content
@@ -887,6 +890,8 @@ struct DevSink {
 
 	uint32_t cbase, cleft;      // copy slots taken eight at a time (one atomic), unused ones are cleared
 	uint64_t lit_abs = 0;       // ztmp offset of the frame's literals space
+	uint32_t ntree_mine = 0;    // trees of this frame so far
+	uint32_t nreads = 0;        // reads of the batch
 	uint32_t first_xblk = 0, cur_xblk = 0, seq0 = 0; // blocks with sequences: the frame's chain, the one being filled
 
 	__device__ uint32_t take(uint32_t *ctr, uint32_t n = 1)
@@ -938,8 +943,8 @@ struct DevSink {
 	{
 		if (!n)
 			return;
-		if (!cleft) {
-			cbase = take(&z.dctl->ncopy, 8);
+		if (!cleft) { // (a read's first ZCOPY_OWN pieces have slots of their own: k_zs_walk)
+			cbase = ZCOPY_OWN * nreads + take(&z.dctl->ncopy, 8);
 			cleft = 8;
 		}
 		const uint32_t i = cbase++;
@@ -1016,7 +1021,10 @@ struct DevSink {
 	__device__ int64_t tree(const uint8_t *w, uint32_t tl)
 	{
 		close_unit();
-		const uint32_t i = take(&z.dctl->ntrees);
+		// a read's first tree is slot `read` of the list (no counter), the others follow the reads' slots
+		uint32_t i = read;
+		if (ntree_mine++)
+			i = nreads + take(&z.dctl->ntrees);
 		if (i >= z.cap_trees)
 			return zs::W_HOST;
 		ZsTree *t = z.dtree + i;
@@ -1083,12 +1091,23 @@ __device__ uint32_t g_walk_ticks[8192]; // k_zs_walk: s_memtime ticks of read r'
 #ifndef ZSWALK_WAVES
 #define ZSWALK_WAVES 4
 #endif
-__global__ __launch_bounds__(256, ZSWALK_WAVES) void k_zs_walk(DecodeArgs a, ZsBufs z)
+// LEAN: the walk of frames without sequences (this library's own) - under 1 KB of scratch per read and half the
+// registers, so that every read of a batch has its wave resident at once (the walk is a chain of memory round trips:
+// with 16 waves per CU a batch of 8192 reads went through the chip in two rounds).  It leaves a frame at its first block
+// with sequences (mode 4) to the full walk behind it, whose waves end at once for the reads that are done.
+#ifndef ZSWALK_LEAN_WAVES
+#define ZSWALK_LEAN_WAVES 6 // (80 registers; 8 = 64 registers spills: 0.75 ms against 0.55)
+#endif
+template <bool LEAN>
+__global__ __launch_bounds__(256, LEAN ? ZSWALK_LEAN_WAVES : ZSWALK_WAVES) void k_zs_walk(DecodeArgs a, ZsBufs z)
 {
-	__shared__ zs::ReadWork works[4];
-	zs::ReadWork &work = works[threadIdx.x >> 6];
+	using Work = std::conditional_t<LEAN, zs::ReadWorkLean, zs::ReadWork>;
+	__shared__ Work works[4];
+	Work &work = works[threadIdx.x >> 6];
 	const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
 	if (r >= a.nreads)
+		return;
+	if (!LEAN && z.rd[r].mode != 4)
 		return;
 #ifdef HUF_STAMPS
 	const unsigned long long wt0 = __builtin_amdgcn_s_memtime();
@@ -1097,6 +1116,9 @@ __global__ __launch_bounds__(256, ZSWALK_WAVES) void k_zs_walk(DecodeArgs a, ZsB
 	const uint64_t cap = zs_content_max(cap_n, z.kdiv); // what zs_slot() leaves room for
 	DevSink sink{ z, a.in_off[r], z.zoff[r], r, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, false, 0, 0 };
 	sink.lit_abs = z.lit_base + z.zoff[r];
+	sink.nreads = a.nreads;
+	sink.cbase = ZCOPY_OWN * r;
+	sink.cleft = ZCOPY_OWN;
 #ifdef HUF_STAMPS
 	sink.st_t = wt0;
 #endif
@@ -1120,7 +1142,7 @@ __global__ __launch_bounds__(256, ZSWALK_WAVES) void k_zs_walk(DecodeArgs a, ZsB
 	rd.pad[0] = L >= 0 ? sink.first_xblk : 0;
 	rd.pad[1] = 0;
 	rd.nd = L >= 0 ? (uint32_t) L : 0;
-	rd.mode = L >= 0 ? 0 : L == zs::W_HOST ? 3 : 2;
+	rd.mode = L >= 0 ? 0 : L == zs::W_HOST ? 3 : L == zs::W_SEQ ? 4 : 2;
 	z.rd[r] = rd;
 	if (rd.mode == 3)
 		atomicAdd(&z.dctl->nhost, 1u);
@@ -1161,7 +1183,8 @@ __device__ __forceinline__ void copy_piece(const DecodeArgs &a, const ZsBufs &z,
 
 __global__ __launch_bounds__(256) void k_zs_copy(DecodeArgs a, ZsBufs z)
 {
-	const uint32_t total = z.dctl->ncopy < z.cap_copy ? z.dctl->ncopy : z.cap_copy;
+	const uint64_t queued = (uint64_t) ZCOPY_OWN * a.nreads + z.dctl->ncopy;
+	const uint32_t total = queued < z.cap_copy ? (uint32_t) queued : z.cap_copy;
 	for (uint32_t i = blockIdx.x; i < total; i += gridDim.x)
 		copy_piece(a, z, z.dcopy[i]);
 }
@@ -1546,7 +1569,8 @@ void launch_zstd_decode_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t
 		return;
 	(void) hipMemsetAsync(z.dctl, 0, sizeof(ZsDCtl), s);
 	hipLaunchKernelGGL(k_zs_layout, dim3(1), dim3(1024), 0, s, a.nsamp, a.nreads, z.zoff, z.zoff4, z.kdiv);
-	hipLaunchKernelGGL(k_zs_walk, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
+	hipLaunchKernelGGL(k_zs_walk<true>, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
+	hipLaunchKernelGGL(k_zs_walk<false>, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_copy, dim3(z.cap_copy < 8192 ? z.cap_copy : 8192), dim3(256), 0, s, a, z);
 	ktime_begin(1, s);
 	hipLaunchKernelGGL(k_zs_hdecode, dim3((z.cap_units + 1) / 2), dim3(64), 0, s, a, z);

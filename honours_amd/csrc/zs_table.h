@@ -581,7 +581,9 @@ struct SeqTab {
 	uint32_t log;   // table log; 0 with one entry: an RLE table
 	uint32_t valid;
 };
-struct ReadWork {
+// (what a frame WITHOUT sequences needs - this library's own frames: under 1 KB, so that a CU holds a wave for every read of
+// a batch; a walk with this scratch leaves frames with sequences to a second walk, W_SEQ)
+struct ReadWorkLean {
 	uint8_t win[WIN];
 	uint8_t w[256];
 	uint8_t desc[DESC_MAX + 4];
@@ -589,6 +591,8 @@ struct ReadWork {
 	uint32_t dtab[64]; // FSE decoding table of the weights: value | bits << 8 | (next state's base) << 16
 	uint16_t next[16];
 	int norm[16];
+};
+struct ReadWork : ReadWorkLean {
 	// sequences
 	SeqTab st[3];      // literal lengths, offsets, match lengths
 	int norm2[64];
@@ -597,7 +601,7 @@ struct ReadWork {
 };
 
 // FSE-compressed weights (FSE_decompress with table log <= 6) -> w[0..count); 0: malformed
-ZS_FN uint32_t fse_read_weights(const uint8_t *src, uint32_t len, uint8_t *w, uint32_t max_out, ReadWork &k)
+ZS_FN uint32_t fse_read_weights(const uint8_t *src, uint32_t len, uint8_t *w, uint32_t max_out, ReadWorkLean &k)
 {
 	int *norm = k.norm;
 	uint8_t *dsym = k.dsym;
@@ -717,7 +721,7 @@ ZS_FN uint32_t fse_read_weights(const uint8_t *src, uint32_t len, uint8_t *w, ui
 // (par: lane() / lanes() / sum() / sync() - how the lanes that run the walk together share the
 // loops over the weights; the host has one lane)
 template <class Par>
-ZS_FN uint32_t read_tree(const uint8_t *p, uint32_t avail, uint8_t *w, uint32_t *table_log, ReadWork &k, const Par &par)
+ZS_FN uint32_t read_tree(const uint8_t *p, uint32_t avail, uint8_t *w, uint32_t *table_log, ReadWorkLean &k, const Par &par)
 {
 	if (!avail)
 		return 0;
@@ -995,7 +999,7 @@ ZS_FN uint32_t seq_table(int which, uint32_t mode, const uint8_t *p, uint32_t av
 //   sink.seq_end(tail)                the block's last `tail` literals follow its last match
 // Returns the content size, or W_BAD (malformed) / W_HOST (valid zstd this reader leaves to
 // libzstd: dictionaries, 12-bit tables, several frames, more sequences than the sink takes).
-constexpr int64_t W_BAD = -1, W_HOST = -2;
+constexpr int64_t W_BAD = -1, W_HOST = -2, W_SEQ = -3;
 #if defined(HUF_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
 #define ZS_STAMP(sink, i) (sink).stamp(i) // diagnostic build: where a wave of k_zs_walk spends its time
 #else
@@ -1011,7 +1015,7 @@ template <class Sink> struct FrameSrc {
 	uint64_t len, base;
 	bool valid;
 	Sink &sink;
-	ReadWork &k;
+	ReadWorkLean &k;
 	ZS_FN uint32_t operator[](uint64_t i) // i < len
 	{
 		if (!valid || i < base || i >= base + WIN) {
@@ -1026,8 +1030,12 @@ template <class Sink> struct FrameSrc {
 	}
 };
 
-template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, uint64_t cap, Sink &sink, ReadWork &k)
+// With a ReadWorkLean the walk ends with W_SEQ at the first block that has sequences, before anything of that block is
+// handed to the sink (what the blocks in front of it handed over stays valid: a second walk with a ReadWork hands over the
+// same pieces again).
+template <class Sink, class Work> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, uint64_t cap, Sink &sink, Work &k)
 {
+	constexpr bool SEQS = sizeof(Work) > sizeof(ReadWorkLean);
 	FrameSrc<Sink> f{ fp, len, 0, false, sink, k };
 	if (len < 6 || f[0] != 0x28 || f[1] != 0xB5 || f[2] != 0x2F || f[3] != 0xFD)
 		return W_BAD;
@@ -1120,6 +1128,8 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, 
 				}
 			}
 			const bool seqs = nseq != 0;
+			if (!SEQS && seqs)
+				return W_SEQ;
 			if (!seqs && sq + 1 != end)
 				return W_BAD;
 			if (!seqs && dst + R > cap)
@@ -1173,7 +1183,7 @@ template <class Sink> ZS_FN int64_t walk_frame(const uint8_t *fp, uint64_t len, 
 				}
 			}
 			uint32_t produced = R;
-			if (seqs) {
+			if constexpr (SEQS) if (seqs) {
 				// ---- tables (literal lengths, offsets, match lengths), then the backward bit stream
 				uint64_t q = sq + shl;
 				if (q + 1 > end)

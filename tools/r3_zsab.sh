@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/r3_zsab.sh name... : config 3 bench with tools/bin/libpress_<name>.so, one line each
+# usage: tools/r3_zsab.sh name... : config 3 bench with tools/bin/libpress_<name>.so, one line each (+ kernel times)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 for v in "$@"; do
