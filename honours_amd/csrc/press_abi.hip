@@ -458,7 +458,7 @@ void zs_bufs(ZsBufs &z, uint64_t total_samples, uint32_t nreads, int method = PR
 	z.zn = (uint32_t *) g.zn.p;
 	// what a batch of this library's frames needs, with room for others; a frame that does not
 	// fit (tiny blocks, thousands of trees) goes to libzstd on the host
-	z.cap_copy = z.max_blocks + (uint32_t) (total_samples / 256) + 32 * nreads + 64; // (16 per read are the read's own: ZCOPY_OWN)
+	z.cap_copy = z.max_blocks + (uint32_t) (total_samples / 256) + 16 * nreads + 64;
 	z.cap_units = z.max_blocks / 8 + 2 * nreads + 64;
 	z.cap_trees = 4 * nreads + 64;
 	// frames with sequences (libzstd's own): their literals in the second half of ztmp

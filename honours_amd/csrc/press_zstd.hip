@@ -878,8 +878,7 @@ namespace {
 // Every lane of the wave runs the same walk on the same bytes (uniform control flow, no
 // divergence between reads); lane 0 writes what is found.
 constexpr uint32_t ZU = 8; // Huffman blocks per unit (32 streams: half a wave)
-constexpr uint32_t ZCOPY_OWN = 16; // slots of the copy list every read owns (the count, the key blocks of one of this library's
-                                   // frames: no counter, which all waves of the walk would bump one after the other)
+constexpr uint32_t ZCOPY_INLINE = 2048; // raw blocks up to this size are copied by the walking wave itself
 struct DevSink {
 	const ZsBufs &z;
 	uint64_t in_base, out_base; // arena offset of the frame, ztmp offset of the content
@@ -892,6 +891,7 @@ struct DevSink {
 	uint64_t lit_abs = 0;       // ztmp offset of the frame's literals space
 	uint32_t ntree_mine = 0;    // trees of this frame so far
 	uint32_t nreads = 0;        // reads of the batch
+	const uint8_t *in = nullptr; // the compressed arena
 	uint32_t first_xblk = 0, cur_xblk = 0, seq0 = 0; // blocks with sequences: the frame's chain, the one being filled
 
 	__device__ uint32_t take(uint32_t *ctr, uint32_t n = 1)
@@ -943,8 +943,8 @@ struct DevSink {
 	{
 		if (!n)
 			return;
-		if (!cleft) { // (a read's first ZCOPY_OWN pieces have slots of their own: k_zs_walk)
-			cbase = ZCOPY_OWN * nreads + take(&z.dctl->ncopy, 8);
+		if (!cleft) {
+			cbase = take(&z.dctl->ncopy, 8);
 			cleft = 8;
 		}
 		const uint32_t i = cbase++;
@@ -961,8 +961,48 @@ struct DevSink {
 			overflow = true;
 		}
 	}
-	__device__ void copy(uint64_t src, uint64_t dst, uint32_t n, bool lit) { push_copy(src, dst, n, 0, lit); }
-	__device__ void fill(uint64_t src, uint64_t dst, uint32_t n, bool lit) { push_copy(src, dst, n, 1, lit); }
+	// Fills and short copies are carried out by the walking wave itself (the key blocks of one of this library's frames are a
+	// dozen fills; through the piece list they were 130 000 mostly empty entries for k_zs_copy); only long raw blocks are
+	// queued for k_zs_copy, where a workgroup takes each.  (walk_frame has checked that dst + n stays in the read's slot.)
+	__device__ void copy(uint64_t src, uint64_t dst, uint32_t n, bool lit)
+	{
+		if (n > ZCOPY_INLINE) {
+			push_copy(src, dst, n, 0, lit);
+			return;
+		}
+		uint8_t *d = z.ztmp + (lit ? lit_abs : out_base) + dst;
+		const uint8_t *sp = in + in_base + src;
+		const uint32_t lane = threadIdx.x & 63;
+		for (uint32_t k = lane * 16; k < n; k += 64 * 16) {
+			if (k + 16 <= n) {
+				uint4 v;
+				__builtin_memcpy(&v, sp + k, 16);
+				__builtin_memcpy(d + k, &v, 16);
+			} else {
+				for (uint32_t e = k; e < n; e++)
+					d[e] = sp[e];
+			}
+		}
+	}
+	__device__ void fill(uint64_t src, uint64_t dst, uint32_t n, bool lit)
+	{
+		if (!n)
+			return;
+		uint8_t *d = z.ztmp + (lit ? lit_abs : out_base) + dst;
+		const uint8_t v = in[in_base + src];
+		const uint32_t v4 = v * 0x01010101u, lane = threadIdx.x & 63;
+		// bytes up to a 16-byte boundary, 16 at a time, the rest
+		const uint32_t head = (uint32_t) ((16 - ((uintptr_t) d & 15)) & 15);
+		const uint32_t h = head < n ? head : n;
+		if (lane < h)
+			d[lane] = v;
+		const uint32_t mid = (n - h) / 16;
+		for (uint32_t k = lane; k < mid; k += 64)
+			*reinterpret_cast<uint4 *>(d + h + 16ull * k) = make_uint4(v4, v4, v4, v4);
+		const uint32_t rest = h + 16 * mid + lane;
+		if (rest < n)
+			d[rest] = v;
+	}
 	// a block with sequences: a record of its own, chained to the frame's earlier ones, and room for
 	// its sequences (k_zs_exec carries them out)
 	__device__ int64_t seq_block(uint32_t nseq, uint64_t lit, uint32_t R, uint64_t dst)
@@ -1117,8 +1157,7 @@ __global__ __launch_bounds__(256, LEAN ? ZSWALK_LEAN_WAVES : ZSWALK_WAVES) void 
 	DevSink sink{ z, a.in_off[r], z.zoff[r], r, 0xFFFFFFFFu, 0xFFFFFFFFu, 0, false, 0, 0 };
 	sink.lit_abs = z.lit_base + z.zoff[r];
 	sink.nreads = a.nreads;
-	sink.cbase = ZCOPY_OWN * r;
-	sink.cleft = ZCOPY_OWN;
+	sink.in = a.in;
 #ifdef HUF_STAMPS
 	sink.st_t = wt0;
 #endif
@@ -1183,8 +1222,7 @@ __device__ __forceinline__ void copy_piece(const DecodeArgs &a, const ZsBufs &z,
 
 __global__ __launch_bounds__(256) void k_zs_copy(DecodeArgs a, ZsBufs z)
 {
-	const uint64_t queued = (uint64_t) ZCOPY_OWN * a.nreads + z.dctl->ncopy;
-	const uint32_t total = queued < z.cap_copy ? (uint32_t) queued : z.cap_copy;
+	const uint32_t total = z.dctl->ncopy < z.cap_copy ? z.dctl->ncopy : z.cap_copy;
 	for (uint32_t i = blockIdx.x; i < total; i += gridDim.x)
 		copy_piece(a, z, z.dcopy[i]);
 }
