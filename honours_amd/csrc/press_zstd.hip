@@ -1263,8 +1263,11 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 		uint16_t *dt = dt2[hh];
 		// ---- table: bytes in the order of the weights (zs::huf_build_dtable), all lanes fill
 		uint32_t w4[4], rank[4];
-		for (int i = 0; i < 4; i++)
-			w4[i] = t->w[4 * lane + i];
+		{
+			const uint32_t four = reinterpret_cast<const uint32_t *>(t->w)[lane];
+			for (int i = 0; i < 4; i++)
+				w4[i] = (four >> (8 * i)) & 0xFFu;
+		}
 		uint32_t start_x[12];
 		uint32_t at = 0;
 		for (uint32_t x = 1; x <= 11; x++) {
@@ -1292,13 +1295,25 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 		}
 		if (at != (1u << tl) || tl > 11) // cannot happen: read_tree checked the weights
 			continue;
-		for (int sl = 0; sl < 64; sl++)
-			for (int i = 0; i < 4; i++) {
-				const uint32_t s0 = __shfl(st[i], sl) << (11 - tl), n0 = __shfl(nn[i], sl) << (11 - tl), x0 = __shfl(w4[i], sl);
-				const uint32_t e = (uint32_t) (4 * sl + i) | ((tl + 1 - x0) << 8);
-				for (uint32_t k = lane; k < n0; k += 64)
+		// a byte's run of entries: up to 16 by the lane that owns the byte (most bytes have long codes: short runs), the
+		// longer ones by all lanes, one run after the other (one run after the other for all 256 bytes: 10 % of the
+		// kernel's wave time)
+		for (int i = 0; i < 4; i++) {
+			const uint32_t s0 = st[i] << (11 - tl), n0 = nn[i] << (11 - tl);
+			const uint32_t e = (uint32_t) (4 * lane + i) | ((tl + 1 - w4[i]) << 8);
+			if (n0 <= 16)
+				for (uint32_t k = 0; k < n0; k++)
 					dt[s0 + k] = (uint16_t) e;
+			unsigned long long big = __ballot(n0 > 16);
+			while (big) {
+				const int sl = __builtin_ctzll(big);
+				big &= big - 1;
+				const uint32_t s1 = (uint32_t) __builtin_amdgcn_readlane((int) s0, sl), n1 = (uint32_t) __builtin_amdgcn_readlane((int) n0, sl);
+				const uint32_t e1 = (uint32_t) __builtin_amdgcn_readlane((int) e, sl);
+				for (uint32_t k = lane; k < n1; k += 64)
+					dt[s1 + k] = (uint16_t) e1;
 			}
+		}
 		tlh[hh] = tl;
 		cnth[hh] = un.count;
 		readh[hh] = un.read;
