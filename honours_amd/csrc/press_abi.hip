@@ -97,6 +97,8 @@ struct Ctx {
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn, dense, dense_off;
 	uint64_t zs_total = 0; // total_samples of the batch in flight (sizes of the zstd scratch)
 	uint32_t zs_nhost = 0; // frames the last zstd depress batch left to libzstd
+	uint32_t *zs_pin = nullptr; // page-locked: that count comes back while the device goes on with the batch
+	hipEvent_t zs_ev = nullptr;
 	// static Huffman table currently on the device
 	bool have_table = false;
 	bool table_trie = false; // some code of the table is beyond the second-level tables (HUF_NEEDS_TRIE)
@@ -657,6 +659,12 @@ extern "C" void press_hip_shutdown(void)
 	for (DevBuf *b = g_bufs; b; b = b->next)
 		b->release();
 	staging_release();
+	if (g.zs_pin)
+		(void) hipHostFree(g.zs_pin);
+	if (g.zs_ev)
+		(void) hipEventDestroy(g.zs_ev);
+	g.zs_pin = nullptr;
+	g.zs_ev = nullptr;
 	g.zs_total = 0;
 	(void) hipStreamDestroy(g.own);
 	g.own = nullptr;
@@ -1006,17 +1014,31 @@ static int launch_press(int method, const BatchArgs &a, hipStream_t s)
 	return 0;
 }
 
-// Frames the device walk leaves to libzstd (sequences, dictionaries, 12-bit tables ...): their
-// content is made on the host and put where the device would have put it.  Costs one stream
-// synchronisation per batch; a batch of this library's own frames has none of them.
-static int zs_host_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t s)
+// Frames the device walk leaves to libzstd (dictionaries, 12-bit tables, several frames in one stream ...): their
+// content is made on the host and put where the device would have put it.  How many there are comes back through a
+// page-locked word behind an event (zs_count_host_frames, queued between the two stages of a batch): the host waits for
+// that word only, while the device already runs the second stage - a batch of this library's own frames, or of
+// ZSTD_compress's, has no such frame and is never waited for; with one, the second stage is run again (*patched).
+static int zs_count_host_frames(const ZsBufs &z, hipStream_t s)
 {
-	uint32_t nhost = 0;
-	HIPCHK(hipMemcpyAsync(&nhost, &z.dctl->nhost, sizeof nhost, hipMemcpyDeviceToHost, s));
-	HIPCHK(hipStreamSynchronize(s));
+	if (!g.zs_pin) {
+		HIPCHK(hipHostMalloc((void **) &g.zs_pin, 64, hipHostMallocDefault));
+		HIPCHK(hipEventCreateWithFlags(&g.zs_ev, hipEventDisableTiming));
+	}
+	HIPCHK(hipMemcpyAsync(g.zs_pin, &z.dctl->nhost, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	HIPCHK(hipEventRecord(g.zs_ev, s));
+	return 0;
+}
+static int zs_host_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t s, bool *patched)
+{
+	*patched = false;
+	HIPCHK(hipEventSynchronize(g.zs_ev));
+	const uint32_t nhost = *g.zs_pin;
 	g.zs_nhost = nhost;
 	if (!nhost || !zstd_open())
 		return 0; // without libzstd those reads fail
+	HIPCHK(hipStreamSynchronize(s)); // (the second stage is running on what the device had)
+	*patched = true;
 	const uint32_t nr = a.nreads;
 	std::vector<ZsRead> rd(nr);
 	std::vector<uint64_t> ioff(nr), ilen(nr), zoff(nr + 1);
@@ -1066,10 +1088,15 @@ static int launch_depress(int method, const DecodeArgs &a, hipStream_t s)
 		ZsBufs z;
 		zs_bufs(z, g.zs_total, a.nreads, method);
 		launch_zstd_decode_frames(a, z, s);
-		const int rc = zs_host_frames(a, z, s);
+		int rc = zs_count_host_frames(z, s);
 		if (rc)
 			return rc;
 		launch_zstd_decode_streams(a, z, s);
+		bool patched;
+		if ((rc = zs_host_frames(a, z, s, &patched)))
+			return rc;
+		if (patched)
+			launch_zstd_decode_streams(a, z, s);
 		break;
 	}
 	default:

@@ -284,8 +284,10 @@ int press_hip_depress_batch(int method, const uint8_t *in, const uint64_t *in_of
  *            the blocks, the literals are decoded in parallel, one wave per frame carries out its
  *            sequences.  Only frames with a dictionary, a 12-bit Huffman table, more sequences than the
  *            scratch takes, or several frames in one stream are decompressed by libzstd on the host
- *            inside the call.  NOTE: a zstd depress batch always synchronises the stream once (the
- *            count of such frames is read back), also when device_resident != 0.
+ *            inside the call.  NOTE: a zstd depress call waits on the host until the frames have been
+ *            walked (the count of such frames comes back through page-locked memory behind an event), also
+ *            when device_resident != 0 - the device meanwhile goes on with the rest of the batch, and the
+ *            call does not wait for that; only a batch WITH such frames synchronises the stream.
  *            n[r] is the room in samples; the count in the stream decides (press.c:1901).  Content
  *            checksums are not verified.
  */
