@@ -342,7 +342,24 @@ struct WavePar {
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	}
 	__device__ void inc(uint32_t *p) const { atomicAdd(p, 1u); }
+#ifdef HUF_STAMPS
+	unsigned long long *last; // (LDS, per wave)
+	__device__ void stamp(int i) const;
+#else
+	__device__ void stamp(int) const {}
+#endif
 };
+#ifdef HUF_STAMPS
+__device__ unsigned long long g_tstamp[8];
+__device__ void WavePar::stamp(int i) const
+{
+	if (l == 0) {
+		const unsigned long long n = __builtin_amdgcn_s_memtime();
+		atomicAdd(&g_tstamp[i], n - *last);
+		*last = n;
+	}
+}
+#endif
 
 // one wave per read: the Huffman table from the histogram, and the ranks of the key lists
 struct TabLds {
@@ -354,6 +371,14 @@ __global__ __launch_bounds__(256) void k_zs_table(BatchArgs a, ZsBufs z)
 {
 	__shared__ TabLds lds[4];
 	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#ifdef HUF_STAMPS
+	__shared__ unsigned long long tlast[4];
+	if (lane == 0)
+		tlast[w] = __builtin_amdgcn_s_memtime();
+	const WavePar wpar{ (uint32_t) lane, &tlast[w] };
+#else
+	const WavePar wpar{ (uint32_t) lane };
+#endif
 	const uint32_t r = blockIdx.x * 4 + w;
 	if (r >= a.nreads)
 		return;
@@ -419,7 +444,9 @@ __global__ __launch_bounds__(256) void k_zs_table(BatchArgs a, ZsBufs z)
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-	zs::build_table(cnt, L.order, present, L.t, L.k, WavePar{ (uint32_t) lane });
+	wpar.stamp(0); // key ranks, counts, order
+	zs::build_table(cnt, L.order, present, L.t, L.k, wpar);
+	wpar.stamp(6); // (direct description / the rest)
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1652,6 +1679,10 @@ void launch_zstd_decode_streams(const DecodeArgs &a, const ZsBufs &z, hipStream_
 } // namespace ph
 
 #ifdef HUF_STAMPS
+extern "C" int press_hip_zs_table_stamps(unsigned long long *dst)
+{
+	return hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(dst, HIP_SYMBOL(ph::g_tstamp), 64) == hipSuccess ? 0 : -1;
+}
 extern "C" int press_hip_zs_walk_stamps(unsigned long long *dst)
 {
 	return hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(dst, HIP_SYMBOL(ph::g_wstamp), 64) == hipSuccess ? 0 : -1;

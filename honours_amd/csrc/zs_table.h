@@ -119,6 +119,7 @@ struct Solo {
 	ZS_FN uint32_t lanes() const { return 1; }
 	ZS_FN void sync() const {}
 	ZS_FN void inc(uint32_t *p) const { ++*p; }
+	ZS_FN void stamp(int) const {} // (the device's diagnostic build: where a wave of k_zs_table spends its time)
 };
 
 // cnt[256]: occurrences; order[0..m): the bytes with cnt > 0, ascending by (cnt, byte); m >= 2.
@@ -164,6 +165,7 @@ template <class Par> ZS_FN void build_table(const uint32_t *cnt, const uint8_t *
 		k.parent[root] = (uint16_t) root;
 	}
 	par.sync();
+	par.stamp(1); // the tree
 	// ---- depths.  One lane: from the root down (a parent has a larger index than its children).
 	// Many lanes: pointer jumping - every node doubles the distance to its marked ancestor,
 	// eight times for up to 255 levels.
@@ -202,6 +204,7 @@ template <class Par> ZS_FN void build_table(const uint32_t *cnt, const uint8_t *
 		par.inc(&bl[d > (uint32_t) MAXLEN ? (uint32_t) MAXLEN : d]);
 	}
 	par.sync();
+	par.stamp(2); // depths
 	// ---- the clamp oversubscribes the code space by `debt` (units of 2^-MAXLEN).  Pay it back
 	// where it is cheapest: making the rarest byte of the d-bit class one bit longer frees
 	// 2^(MAXLEN-1-d) units for cnt bits; whatever was freed too much is spent on the most
@@ -283,6 +286,7 @@ template <class Par> ZS_FN void build_table(const uint32_t *cnt, const uint8_t *
 		}
 	}
 	par.sync();
+	par.stamp(3); // the length limit
 	if (k.fail)
 		return;
 	const uint32_t tl = t.table_log;
@@ -308,6 +312,7 @@ template <class Par> ZS_FN void build_table(const uint32_t *cnt, const uint8_t *
 		const uint32_t wt = tl + 1 - l;
 		t.code[s] = (uint16_t) ((k.cum[wt] >> (wt - 1)) + rank);
 	}
+	par.stamp(4); // lengths, codes
 	// ---- tree description: the weights of bytes 0 .. last-1 (the last one is implied)
 	int last = 255;
 	while (!t.len[last])
@@ -462,6 +467,7 @@ template <class Par> ZS_FN void build_table(const uint32_t *cnt, const uint8_t *
 			t.ok = 1;
 		}
 	}
+	par.stamp(5); // the description (FSE)
 	par.sync();
 }
 

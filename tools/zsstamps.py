@@ -43,3 +43,11 @@ wn = ["window fetches", "raw / RLE pieces queued", "tree description fetched", "
 tot = float(ws.sum())
 for i, nme in enumerate(wn):
     print("walk %-28s %14d ticks  %5.1f %%" % (nme, int(ws[i]), 100.0 * int(ws[i]) / tot))
+
+ts = np.zeros(8, dtype=np.uint64)
+lib.press_hip_zs_table_stamps.argtypes = [ctypes.c_void_p]
+assert lib.press_hip_zs_table_stamps(ts.ctypes.data) == 0
+tn = ["key ranks, counts, order", "tree (two queues)", "depths", "length limit", "lengths, codes", "description (FSE)", "rest (direct description)"]
+tot = float(ts.sum())
+for i, nme in enumerate(tn):
+    print("table %-28s %14d ticks  %5.1f %%" % (nme, int(ts[i]), 100.0 * int(ts[i]) / tot))
