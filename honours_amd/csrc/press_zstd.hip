@@ -1254,13 +1254,7 @@ __global__ __launch_bounds__(256) void k_zs_copy(DecodeArgs a, ZsBufs z)
 		copy_piece(a, z, z.dcopy[i]);
 }
 
-#ifndef HD_SYMS_N
-#define HD_SYMS_N 64
-#define HD_IN_N 96
-#endif
-constexpr uint32_t HD_SYMS = HD_SYMS_N; // bytes decoded per round
-constexpr uint32_t HD_IN = HD_IN_N;     // stream bytes staged per round: HD_SYMS codes of at most 11 bits, 11 more, whole 16 bytes
-static_assert(HD_SYMS % 16 == 0 && HD_IN % 16 == 0 && 8 * HD_IN >= 11 * HD_SYMS + 11 + 7, "a round's codes are staged");
+constexpr uint32_t HD_SYMS = 32; // codes per round: at most 44 bytes + 12 bits of look-ahead, less than a 64-byte chunk
 // one wave per PAIR of units (a unit = up to ZU blocks of one read = 32 streams; the mean read has
 // 7 blocks, so whole waves per read would leave more than half of the lanes idle - and the
 // kernel is bound by the instructions per decoded byte, not by latency): two tables in LDS,
@@ -1270,8 +1264,7 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	// the two tables, always indexed by 11 stream bits (a shorter table log: every entry 2^(11 - log) times), each on a
 	// 4096-byte boundary: a look-up's LDS address is (window & 0xFFE) | base - one instruction
 	__shared__ __attribute__((aligned(4096))) uint16_t dt2[2][2048];
-	__shared__ uint32_t sin[64][HD_IN / 4 + 3];   // odd stride (27): a lane's slot starts in its own bank; one dword
-	                                              // of zeros in front of the bytes, one behind (a pair is read)
+	__shared__ uint32_t ring[64][33]; // a lane's 128 stream bytes (odd stride: a lane's ring starts in its own bank)
 	const uint32_t total = z.dctl->nunits < z.cap_units ? z.dctl->nunits : z.cap_units;
 	if (2 * blockIdx.x >= total)
 		return;
@@ -1395,77 +1388,111 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 			active = false;
 		}
 	}
-	// The stream is read backwards from its end mark: bp = stream bits not yet used.  No 64-bit bit
-	// window (its shifts run at a quarter of the rate and made this kernel VALU bound): the 11 bits below
-	// bp are cut out of two staged dwords that stay in registers.
+	// The stream is read backwards from its end mark: bp = stream bits not yet used.  No 64-bit bit window (its shifts run at
+	// a quarter of the rate): the 11 bits below bp are cut out of two dwords that stay in registers.
 	// (Measured and dropped, round 2: a two-symbol table over 10 index bits, as much LDS as this one - 1.55
 	// symbols per step, but with its longer step 2.05 .. 2.3 ms against 1.83 ms.)
+	//
+	// Stream bytes come through a RING of 128 bytes per lane: the byte at (the low bits of) global address A sits at ring
+	// byte A & 127 - two 64-byte chunks on 64-byte boundaries, each fetched ONCE, whole, and a round ahead of its use.
+	// (Windows of 96 bytes at any byte address, staged again every round, fetched 2.2 GB for 0.43 GB of streams and put a
+	// memory round trip in front of every round: without them the kernel took 0.93 instead of 1.22 - 1.45 ms.)
+	// A round is HD_SYMS = 32 codes: at most 44 bytes and 12 bits of look-ahead - from anywhere in the upper chunk that stays
+	// inside the lower one.  When the position has moved into the lower chunk, the chunk below it (asked for at the round's
+	// start, in registers since) replaces the upper one; the round's bytes are stored BEHIND that, so that the wait for
+	// the chunk is not a wait for those stores (the memory counter is in order).
 	int32_t bp = 0;
 	bool overrun = false;
 	if (active)
 		bp = (int32_t) (8 * (len - 1)) + (31 - __builtin_clz((uint32_t) p[len - 1]));
-	uint32_t *myin = sin[lane];
-	myin[0] = 0; // stream byte base + j of a round sits at slot byte 4 + j: bits "below the stream" read as zeros
-	ZSTAMP(1); // stream headers
+	uint32_t *myring = ring[lane];
+	const uint32_t ap = (uint32_t) (uintptr_t) p & 0x07FFFFFFu; // (low address bits: 8 ap + the stream's bits stay below 2^31)
+	// 16 bytes of chunk address ca (low bits; a multiple of 16) -> registers: whole pieces inside the stream by one load,
+	// the stream's first and last piece byte by byte, what lies outside reads as zeros
+	// (whole = inside the stream's FRAME: what a stream's first and last piece hold of its neighbours is never used, and
+	// byte by byte those two pieces of every stream cost a quarter of a wave's time)
+	int32_t flo = 0, fhi = (int32_t) len; // the frame's bytes, as offsets in the stream
+	if (active && un.read < a.nreads) {
+		const int64_t f0 = (int64_t) a.in_off[un.read] - (int64_t) (p - a.in);
+		const int64_t f1 = f0 + (int64_t) a.in_len[un.read];
+		if (f0 <= 0 && f1 >= (int64_t) len && f0 > -0x40000000ll && f1 < 0x40000000ll) {
+			flo = (int32_t) f0;
+			fhi = (int32_t) f1;
+		}
+	}
+	auto piece = [&](uint32_t ca) -> uint4 {
+		const int32_t o = (int32_t) (ca - ap); // offset of the piece in the stream
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (o >= flo && o + 16 <= fhi) {
+			__builtin_memcpy(&v, p + o, 16);
+		} else if (o > -16 && o < (int32_t) len) {
+			uint32_t x[4] = { 0, 0, 0, 0 };
+			for (int e = 0; e < 16; e++)
+				if (o + e >= 0 && o + e < (int32_t) len)
+					x[e >> 2] |= (uint32_t) p[o + e] << (8 * (e & 3));
+			v = make_uint4(x[0], x[1], x[2], x[3]);
+		}
+		return v;
+	};
+	auto chunk_to_ring = [&](uint32_t ca, const uint4 *c4) { // chunk address ca (a multiple of 64)
+		uint32_t *d = myring + ((ca >> 2) & 16u);
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			d[4 * j] = c4[j].x;
+			d[4 * j + 1] = c4[j].y;
+			d[4 * j + 2] = c4[j].z;
+			d[4 * j + 3] = c4[j].w;
+		}
+	};
+	// the chunk that holds the stream's highest bit still to come, and the one below it
+	uint32_t cc = 0; // (address of the upper chunk)
+	if (active) {
+		cc = (ap + (uint32_t) ((bp > 0 ? bp - 1 : 0) >> 3)) & ~63u;
+		uint4 c4[4];
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+			c4[j] = piece(cc + 16 * j);
+		chunk_to_ring(cc, c4);
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+			c4[j] = piece(cc - 64 + 16 * j);
+		chunk_to_ring(cc - 64, c4);
+	}
+	// sp = the (address-based) bit position ONE BELOW the eleven bits a look-up wants: the window cut at sp has the table
+	// index in bits 1 .. 11 - twice the index, the entry's byte offset.  The chain from one code to the next is cut -
+	// mask/or - look-up - subtract - clamp - dword test - select: the clamp at the stream's bit 0 replaces a compare and a
+	// select, the bits are also summed next to the chain and compared with what the stream had when the round is over.
+	const int32_t c0 = (int32_t) (8 * ap) - 12;
+	int32_t sp = bp + c0;
+	uint32_t w0 = (uint32_t) sp >> 5;
+	uint32_t lo = myring[w0 & 31u], hi = myring[(w0 + 1) & 31u];
+	uint4 pre[4]; // the chunk below the ring's two
+	bool have_pre = false;
+#pragma unroll
+	for (int j = 0; j < 4; j++)
+		pre[j] = make_uint4(0, 0, 0, 0);
+	ZSTAMP(1); // stream headers, first chunks
 	for (uint32_t done = 0; __any(active && done < k); done += HD_SYMS) {
 		const bool go = active && done < k;
 		const uint32_t cnt = go ? (k - done < HD_SYMS ? k - done : HD_SYMS) : 0;
-		// the HD_IN stream bytes up to the one that holds bit bp - 1; a round of 64 codes uses at
-		// most 704 + 11 bits of them
-		const int32_t tb = bp > 0 ? (bp - 1) >> 3 : 0;
-		const int32_t base = tb >= (int32_t) HD_IN - 1 ? tb - ((int32_t) HD_IN - 1) : 0;
-		// six lanes share a stream's 96 bytes (16 each): a load instruction then reads ~11 runs
-		// of 96 bytes instead of 64 scattered pieces
-		{
-			const uint64_t pb = go ? (uint64_t) (uintptr_t) (p + base) : 0;
-			const uint32_t avail = go ? (uint32_t) ((int32_t) len - base < (int32_t) HD_IN ? (int32_t) len - base : (int32_t) HD_IN) : 0;
-			uint4 v[HD_IN / 16];
-			int oo[HD_IN / 16], kk[HD_IN / 16];
+		if (go && !have_pre) { // asked for now, wanted a round or more from now
+			const int32_t o = (int32_t) (cc - 128 - ap);
+			if (o >= flo && o + 64 <= fhi) { // (the rule: the whole chunk is inside the frame)
 #pragma unroll
-			for (int c = 0; c < (int) HD_IN / 16; c++) {
-				const int g = 64 * c + lane;
-				oo[c] = g / (int) (HD_IN / 16);
-				kk[c] = g - (int) (HD_IN / 16) * oo[c];
-				const uint64_t opb = ((uint64_t) (uint32_t) __shfl((int) (pb >> 32), oo[c]) << 32) | (uint32_t) __shfl((int) pb, oo[c]);
-				const uint32_t oav = (uint32_t) __shfl((int) avail, oo[c]);
-				v[c] = make_uint4(0, 0, 0, 0);
-				if (16u * kk[c] + 16u <= oav)
-					__builtin_memcpy(&v[c], (const uint8_t *) (uintptr_t) opb + 16 * kk[c], 16);
-			}
+				for (int j = 0; j < 4; j++)
+					__builtin_memcpy(&pre[j], p + o + 16 * j, 16);
+			} else {
 #pragma unroll
-			for (int c = 0; c < (int) HD_IN / 16; c++) {
-				uint32_t *row = sin[oo[c]] + 1 + 4 * kk[c];
-				row[0] = v[c].x;
-				row[1] = v[c].y;
-				row[2] = v[c].z;
-				row[3] = v[c].w;
+				for (int j = 0; j < 4; j++)
+					pre[j] = piece(cc - 128 + 16 * j);
 			}
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			have_pre = true;
 		}
-		if (go && base == 0 && len < HD_IN) { // a short stream: its last, partial 16 bytes one by one
-			for (uint32_t e = len & ~15u; e < len; e++) {
-				const uint32_t b = p[e], at = e + 4;
-				myin[at >> 2] = (myin[at >> 2] & ~(0xFFu << (8 * (at & 3)))) | (b << (8 * (at & 3)));
-			}
-		}
-		ZSTAMP(2); // staging
-		// sp = the slot bit ONE BELOW the eleven bits a look-up wants (stream bit b sits at slot bit b + 32 - 8 base): the
-		// window cut at sp has the table index in bits 1 .. 11 - twice the index, the entry's byte offset.  The chain
-		// from one code to the next is cut - mask/or - look-up - subtract - clamp - dword test - select: the clamp at
-		// the stream's bit 0 replaces a compare and a select, the bits are also summed next to the chain and compared
-		// with what the stream had when the round is over (1.52 -> ms).
-		const int32_t c0 = 32 - 11 - 1 - 8 * base;
+		ZSTAMP(2); // the next chunk asked for
 		const int32_t bp0 = bp;
-		int32_t sp = bp + c0;
 		uint32_t used = 0;
-		// the two dwords around slot bit sp stay in registers; the dword below them is fetched while
-		// the table look-up is in flight (a step moves down by at most 11 bits: at most one dword)
-		uint32_t w0 = (uint32_t) sp >> 5;
-		uint32_t lo = myin[w0], hi = myin[w0 + 1];
 		auto step = [&]() -> uint32_t { // one code: its byte
-			const uint32_t below = myin[w0 ? w0 - 1 : 0];
+			const uint32_t below = myring[(w0 - 1) & 31u];
 			const uint32_t y = __builtin_amdgcn_alignbit(hi, lo, (uint32_t) sp); // shift = low 5 bits
 			const uint32_t e = *(lds_cu16p) (uintptr_t) ((y & 0xFFEu) | dtb);
 			const uint32_t nb = e >> 8;
@@ -1479,46 +1506,55 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 			w0 = wn;
 			return e & 0xFFu;
 		};
-		// ---- sixteen codes at a time, their bytes stored from registers: 16 bytes per lane and store.  (Through an
-		// LDS slot per lane and stores shared by four lanes - 64-byte runs - the slots were 4.3 KB of a wave's 19 KB:
-		// 8 waves per CU; scattered DWORD stores had cost as much as the decoding.)
-		uint8_t *o = out + done;
-		if (!__any(go && cnt != HD_SYMS)) { // every stream of the wave that is still running has a whole round
-			if (go) {
-				for (uint32_t g = 0; g < HD_SYMS / 16; g++) {
-					uint32_t a4[4] = { 0, 0, 0, 0 };
+		// ---- sixteen codes at a time into registers
+		uint32_t all[HD_SYMS / 4];
 #pragma unroll
-					for (int j = 0; j < 16; j++)
-						a4[j >> 2] |= step() << (8 * (j & 3));
-					const uint4 v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
-					__builtin_memcpy(o + 16 * g, &v, 16);
-				}
+		for (int i = 0; i < (int) HD_SYMS / 4; i++)
+			all[i] = 0;
+		const bool whole = !__any(go && cnt != HD_SYMS); // every stream of the wave that is still running has a whole round
+		if (whole) {
+			if (go) {
+#pragma unroll
+				for (int j = 0; j < (int) HD_SYMS; j++)
+					all[j >> 2] |= step() << (8 * (j & 3));
 			}
 		} else { // a stream's last, short round
-			for (uint32_t g = 0; g < HD_SYMS / 16; g++) {
-				uint32_t a4[4] = { 0, 0, 0, 0 };
 #pragma unroll
-				for (int j = 0; j < 16; j++)
-					if (16 * g + j < cnt)
-						a4[j >> 2] |= step() << (8 * (j & 3));
-				if (cnt >= 16 * g + 16) {
-					const uint4 v = make_uint4(a4[0], a4[1], a4[2], a4[3]);
-					__builtin_memcpy(o + 16 * g, &v, 16);
-				} else if (cnt > 16 * g) {
-#pragma unroll
-					for (int j = 0; j < 16; j++)
-						if (16 * g + j < cnt)
-							o[16 * g + j] = (uint8_t) (a4[j >> 2] >> (8 * (j & 3)));
-				}
-			}
+			for (int j = 0; j < (int) HD_SYMS; j++)
+				if ((uint32_t) j < cnt)
+					all[j >> 2] |= step() << (8 * (j & 3));
 		}
 		if (go) {
 			overrun |= used > (uint32_t) bp0; // more code bits than the stream has
 			bp = sp - c0;
 		}
-		ZSTAMP(3); // decode, stores
-		__builtin_amdgcn_wave_barrier();
-		ZSTAMP(4); // stores
+		ZSTAMP(3); // decode
+		// ---- has the position left the upper chunk?  (at most 44 bytes a round: by one chunk)
+		if (go && bp > 0) {
+			const uint32_t cn = (ap + (uint32_t) ((bp - 1) >> 3)) & ~63u;
+			if (cn != cc) {
+				chunk_to_ring(cc - 128, pre);
+				cc -= 64;
+				have_pre = false;
+			}
+		}
+		// ---- the round's bytes out (behind the chunk: see above)
+		if (go) {
+			uint8_t *o = out + done;
+#pragma unroll
+			for (int g = 0; g < (int) HD_SYMS / 16; g++) {
+				if (cnt >= 16u * g + 16u) {
+					const uint4 v = make_uint4(all[4 * g], all[4 * g + 1], all[4 * g + 2], all[4 * g + 3]);
+					__builtin_memcpy(o + 16 * g, &v, 16);
+				} else if (cnt > 16u * g) {
+#pragma unroll
+					for (int j = 0; j < 16; j++)
+						if (16u * g + j < cnt)
+							o[16 * g + j] = (uint8_t) (all[4 * g + (j >> 2)] >> (8 * (j & 3)));
+				}
+			}
+		}
+		ZSTAMP(4); // ring, stores
 	}
 	ZSTAMP_FLUSH();
 	if (active)
