@@ -92,7 +92,7 @@ struct Ctx {
 	bool use_user = false;
 	// scratch shared by both modes
 	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, htrec, hrec, hlist, hread, hwave, hbits, hend, hmin, cbits;
-	DevBuf ztmp, zoff, zoff4, zlen, zhist, ztab, zfirst, zblk, zsbits, zbpos, zbflag, zkcnt, zkbase, zrd, znb, zn, zdcopy, zdhuf, zdunit, zdtree, zdctl, zdseq, zdxblk; // zstd frames
+	DevBuf ztmp, zoff, zoff4, zlen, zhist, ztab, zfirst, zblk, zsbits, zbpos, zbflag, zkcnt, zkbase, zrd, znb, zn, zdcopy, zdhuf, zdunit, zdtree, zdlong, zdctl, zdseq, zdxblk; // zstd frames
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn, dense, dense_off;
 	uint64_t zs_total = 0; // total_samples of the batch in flight (sizes of the zstd scratch)
@@ -456,6 +456,7 @@ void zs_bufs(ZsBufs &z, uint64_t total_samples, uint32_t nreads, int method = PR
 	z.dhuf = (ZsHuf *) g.zdhuf.p;
 	z.dunit = (ZsUnit *) g.zdunit.p;
 	z.dtree = (ZsTree *) g.zdtree.p;
+	z.dlong = (ZsLong *) g.zdlong.p;
 	z.dctl = (ZsDCtl *) g.zdctl.p;
 	z.zn = (uint32_t *) g.zn.p;
 	// what a batch of this library's frames needs, with room for others; a frame that does not
@@ -463,6 +464,7 @@ void zs_bufs(ZsBufs &z, uint64_t total_samples, uint32_t nreads, int method = PR
 	z.cap_copy = z.max_blocks + (uint32_t) (total_samples / 256) + 16 * nreads + 64;
 	z.cap_units = z.max_blocks / 8 + 2 * nreads + 64;
 	z.cap_trees = 4 * nreads + 64;
+	z.cap_long = (uint32_t) (total_samples / 8192) + nreads + 64; // (blocks of at least 32 KiB of literals)
 	// frames with sequences (libzstd's own): their literals in the second half of ztmp
 	z.dseq = (ZsSeq *) g.zdseq.p;
 	z.dxblk = (ZsXBlk *) g.zdxblk.p;
@@ -490,7 +492,7 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 		    g.zlen.reserve(nr * 8) || g.zrd.reserve(nr * sizeof(ZsRead)) || g.zn.reserve(nr * 4) ||
 		    g.zdseq.reserve((size_t) z.cap_seq * sizeof(ZsSeq)) || g.zdxblk.reserve((size_t) z.cap_xblk * sizeof(ZsXBlk)) ||
 		    g.zdcopy.reserve((size_t) z.cap_copy * sizeof(ZsCopy)) || g.zdhuf.reserve((size_t) z.cap_units * 8 * sizeof(ZsHuf)) ||
-		    g.zdunit.reserve((size_t) z.cap_units * sizeof(ZsUnit)) || g.zdtree.reserve((size_t) z.cap_trees * sizeof(ZsTree)) ||
+		    g.zdunit.reserve((size_t) z.cap_units * sizeof(ZsUnit)) || g.zdtree.reserve((size_t) z.cap_trees * sizeof(ZsTree)) || g.zdlong.reserve((size_t) z.cap_long * sizeof(ZsLong)) ||
 		    g.zdctl.reserve(sizeof(ZsDCtl)))
 			return PRESS_HIP_EHIP;
 	}

@@ -218,6 +218,10 @@ struct ZsHuf {                // Huffman-coded literals of one block
 struct ZsUnit {               // up to 8 Huffman blocks of a read with one table: half a wave's work
 	uint32_t read, tree, count, pad;
 };
+struct ZsLong {               // a block with four LONG streams (ZSTD_compress's 128-KiB blocks): a wave of its own, 16 lanes a stream
+	ZsHuf h;
+	uint32_t tree, read, pad[2];
+};
 struct ZsTree {
 	uint8_t w[256];       // weights (RFC 8878 4.2.1.1)
 	uint32_t tl, pad[3];
@@ -240,6 +244,7 @@ struct ZsDCtl { // every counter on a 4-KB page of its own: they are bumped by a
 	uint32_t nseq, pad3[1023];
 	uint32_t nxblk, pad4[1023];
 	uint32_t nhost, pad5[1023];
+	uint32_t nlong, pad6[1023];
 };
 struct ZsBufs {
 	uint8_t *ztmp;        // the svb-zd streams between the two stages: [u32 n][keys][data] of read r at zoff[r]
@@ -263,13 +268,14 @@ struct ZsBufs {
 	ZsHuf *dhuf;          // [cap_units * 8] Huffman blocks, 8 slots per unit
 	ZsUnit *dunit;        // [cap_units]
 	ZsTree *dtree;        // [cap_trees]
+	ZsLong *dlong;        // [cap_long] blocks whose streams are decoded in segments (k_zs_hdecode_long)
 	ZsDCtl *dctl;
 	uint32_t *zn;         // [nreads] sample count found in the stream
 	ZsSeq *dseq;          // [cap_seq] sequences of the frames' blocks
 	ZsXBlk *dxblk;        // [cap_xblk]
 	uint64_t lit_base;    // ztmp offset of the literals space (read r's at lit_base + zoff[r])
 	uint32_t cap_seq, cap_xblk;
-	uint32_t cap_copy, cap_units, cap_trees;
+	uint32_t cap_copy, cap_units, cap_trees, cap_long;
 	uint32_t kdiv;        // samples per key byte of the inner stream: 4 (svb-zd), 8 (svb16-zd), 0: ex-zd (no keys)
 };
 void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s); // press_zstd.hip

@@ -906,6 +906,7 @@ namespace {
 // divergence between reads); lane 0 writes what is found.
 constexpr uint32_t ZU = 8; // Huffman blocks per unit (32 streams: half a wave)
 constexpr uint32_t ZCOPY_INLINE = 2048; // raw blocks up to this size are copied by the walking wave itself
+constexpr uint32_t ZLONG_R = 32768;     // literals of a block from which each of its four streams is decoded by 16 lanes
 struct DevSink {
 	const ZsBufs &z;
 	uint64_t in_base, out_base; // arena offset of the frame, ztmp offset of the content
@@ -1104,6 +1105,25 @@ struct DevSink {
 	}
 	__device__ int64_t huf(uint64_t src, uint32_t cs, uint64_t dst, uint32_t R, bool four, bool lit)
 	{
+		if (four && R >= ZLONG_R) { // four long streams: a wave of its own (k_zs_hdecode_long)
+			const uint32_t i = take(&z.dctl->nlong);
+			if (i >= z.cap_long)
+				return zs::W_HOST;
+			if ((threadIdx.x & 63) == 0) {
+				ZsLong L;
+				L.h.src = in_base + src;
+				L.h.dst = (lit ? lit_abs : out_base) + dst;
+				L.h.cs = cs;
+				L.h.R = R;
+				L.h.four = 1;
+				L.h.pad = 0;
+				L.tree = cur_tree;
+				L.read = read;
+				L.pad[0] = L.pad[1] = 0;
+				z.dlong[i] = L;
+			}
+			return 0;
+		}
 		if (unit == 0xFFFFFFFFu || ucount == ZU) {
 			close_unit();
 			const uint32_t u = take(&z.dctl->nunits);
@@ -1255,6 +1275,68 @@ __global__ __launch_bounds__(256) void k_zs_copy(DecodeArgs a, ZsBufs z)
 }
 
 constexpr uint32_t HD_SYMS = 32; // codes per round: at most 44 bytes + 12 bits of look-ahead, less than a 64-byte chunk
+// The decoding table of a tree in LDS: bytes in the order of the weights (zs::huf_build_dtable), always indexed by 11 stream
+// bits (a shorter table log: every entry 2^(11 - log) times); dt[i] = byte | bits << 8.  All 64 lanes of a wave; false: the
+// weights are not a tree (cannot happen: read_tree checked them).
+__device__ __forceinline__ bool hd_build_table(uint16_t *dt, const ZsTree *t, int lane)
+{
+	const uint32_t tl = t->tl;
+	// ---- table: bytes in the order of the weights (zs::huf_build_dtable), all lanes fill
+	uint32_t w4[4], rank[4];
+	{
+		const uint32_t four = reinterpret_cast<const uint32_t *>(t->w)[lane];
+		for (int i = 0; i < 4; i++)
+			w4[i] = (four >> (8 * i)) & 0xFFu;
+	}
+	uint32_t start_x[12];
+	uint32_t at = 0;
+	for (uint32_t x = 1; x <= 11; x++) {
+		uint32_t mine = 0;
+		for (int i = 0; i < 4; i++) {
+			if (w4[i] == x)
+				rank[i] = mine;
+			mine += w4[i] == x;
+		}
+		const uint32_t inc = wave_incl32(mine, lane);
+		for (int i = 0; i < 4; i++)
+			if (w4[i] == x)
+				rank[i] += inc - mine;
+		start_x[x] = at;
+		at += __shfl(inc, 63) << (x - 1);
+	}
+	uint32_t st[4], nn[4];
+	for (int i = 0; i < 4; i++) {
+		const uint32_t x = w4[i];
+		nn[i] = x ? 1u << (x - 1) : 0;
+		uint32_t base = 0;
+		for (uint32_t y = 1; y <= 11; y++)
+			base = x == y ? start_x[y] : base;
+		st[i] = base + rank[i] * nn[i];
+	}
+	if (at != (1u << tl) || tl > 11) // cannot happen: read_tree checked the weights
+		return false;
+	// a byte's run of entries: up to 16 by the lane that owns the byte (most bytes have long codes: short runs), the
+	// longer ones by all lanes, one run after the other (one run after the other for all 256 bytes: 10 % of the
+	// kernel's wave time)
+	for (int i = 0; i < 4; i++) {
+		const uint32_t s0 = st[i] << (11 - tl), n0 = nn[i] << (11 - tl);
+		const uint32_t e = (uint32_t) (4 * lane + i) | ((tl + 1 - w4[i]) << 8);
+		if (n0 <= 16)
+			for (uint32_t k = 0; k < n0; k++)
+				dt[s0 + k] = (uint16_t) e;
+		unsigned long long big = __ballot(n0 > 16);
+		while (big) {
+			const int sl = __builtin_ctzll(big);
+			big &= big - 1;
+			const uint32_t s1 = (uint32_t) __builtin_amdgcn_readlane((int) s0, sl), n1 = (uint32_t) __builtin_amdgcn_readlane((int) n0, sl);
+			const uint32_t e1 = (uint32_t) __builtin_amdgcn_readlane((int) e, sl);
+			for (uint32_t k = lane; k < n1; k += 64)
+				dt[s1 + k] = (uint16_t) e1;
+		}
+	}
+	return true;
+}
+
 // one wave per PAIR of units (a unit = up to ZU blocks of one read = 32 streams; the mean read has
 // 7 blocks, so whole waves per read would leave more than half of the lanes idle - and the
 // kernel is bound by the instructions per decoded byte, not by latency): two tables in LDS,
@@ -1270,7 +1352,7 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 		return;
 	const int lane = threadIdx.x;
 	ZSTAMP_DECL;
-	uint32_t tlh[2] = { 0, 0 }, cnth[2] = { 0, 0 }, readh[2] = { 0, 0 };
+	uint32_t cnth[2] = { 0, 0 }, readh[2] = { 0, 0 };
 	for (int hh = 0; hh < 2; hh++) {
 		const uint32_t uu = 2 * blockIdx.x + hh;
 		if (uu >= total)
@@ -1278,63 +1360,8 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 		const ZsUnit un = z.dunit[uu];
 		if (un.tree >= z.cap_trees || un.count == 0 || un.count > ZU)
 			continue;
-		const ZsTree *t = z.dtree + un.tree;
-		const uint32_t tl = t->tl;
-		uint16_t *dt = dt2[hh];
-		// ---- table: bytes in the order of the weights (zs::huf_build_dtable), all lanes fill
-		uint32_t w4[4], rank[4];
-		{
-			const uint32_t four = reinterpret_cast<const uint32_t *>(t->w)[lane];
-			for (int i = 0; i < 4; i++)
-				w4[i] = (four >> (8 * i)) & 0xFFu;
-		}
-		uint32_t start_x[12];
-		uint32_t at = 0;
-		for (uint32_t x = 1; x <= 11; x++) {
-			uint32_t mine = 0;
-			for (int i = 0; i < 4; i++) {
-				if (w4[i] == x)
-					rank[i] = mine;
-				mine += w4[i] == x;
-			}
-			const uint32_t inc = wave_incl32(mine, lane);
-			for (int i = 0; i < 4; i++)
-				if (w4[i] == x)
-					rank[i] += inc - mine;
-			start_x[x] = at;
-			at += __shfl(inc, 63) << (x - 1);
-		}
-		uint32_t st[4], nn[4];
-		for (int i = 0; i < 4; i++) {
-			const uint32_t x = w4[i];
-			nn[i] = x ? 1u << (x - 1) : 0;
-			uint32_t base = 0;
-			for (uint32_t y = 1; y <= 11; y++)
-				base = x == y ? start_x[y] : base;
-			st[i] = base + rank[i] * nn[i];
-		}
-		if (at != (1u << tl) || tl > 11) // cannot happen: read_tree checked the weights
+		if (!hd_build_table(dt2[hh], z.dtree + un.tree, lane))
 			continue;
-		// a byte's run of entries: up to 16 by the lane that owns the byte (most bytes have long codes: short runs), the
-		// longer ones by all lanes, one run after the other (one run after the other for all 256 bytes: 10 % of the
-		// kernel's wave time)
-		for (int i = 0; i < 4; i++) {
-			const uint32_t s0 = st[i] << (11 - tl), n0 = nn[i] << (11 - tl);
-			const uint32_t e = (uint32_t) (4 * lane + i) | ((tl + 1 - w4[i]) << 8);
-			if (n0 <= 16)
-				for (uint32_t k = 0; k < n0; k++)
-					dt[s0 + k] = (uint16_t) e;
-			unsigned long long big = __ballot(n0 > 16);
-			while (big) {
-				const int sl = __builtin_ctzll(big);
-				big &= big - 1;
-				const uint32_t s1 = (uint32_t) __builtin_amdgcn_readlane((int) s0, sl), n1 = (uint32_t) __builtin_amdgcn_readlane((int) n0, sl);
-				const uint32_t e1 = (uint32_t) __builtin_amdgcn_readlane((int) e, sl);
-				for (uint32_t k = lane; k < n1; k += 64)
-					dt[s1 + k] = (uint16_t) e1;
-			}
-		}
-		tlh[hh] = tl;
 		cnth[hh] = un.count;
 		readh[hh] = un.read;
 	}
@@ -1568,6 +1595,221 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	}
 }
 
+// Blocks with four LONG streams - ZSTD_compress's own frames, the reference's VBZ streams: 128-KiB blocks, 32 768 codes a
+// stream, and a lane per stream was a chain of 32 768 dependent look-ups (2.5 ms for 2048 reads, most lanes of the chip
+// without work).  Here a wave takes one block and 16 lanes share a stream: Huffman codes synchronise themselves - a decoder
+// started at ANY bit falls into step with the true code boundaries after a few codes - so lane j starts at bit B (16 - j) / 16
+// (lane 0: at the stream's true start), runs down to where lane j + 1 started and notes where it got out; then every lane
+// runs its segment again from where the lane above got out, until no start moves any more (as a rule: once).  The codes of
+// the segments, counted on the way, give every lane its place in the output; a last run writes the bytes.  Same ring, same
+// step as k_zs_hdecode; a step is done under "not yet at the segment's end".
+constexpr int ZSEG = 16;
+__global__ __launch_bounds__(64) void k_zs_hdecode_long(DecodeArgs a, ZsBufs z)
+{
+	__shared__ __attribute__((aligned(4096))) uint16_t dt[2048];
+	__shared__ uint32_t ring[64][33];
+	const uint32_t total = z.dctl->nlong < z.cap_long ? z.dctl->nlong : z.cap_long;
+	const int lane = threadIdx.x;
+	typedef __attribute__((address_space(3))) const uint16_t *lds_cu16p;
+	const uint32_t dtb = (uint32_t) (uintptr_t) (lds_cu16p) dt;
+	uint32_t *myring = ring[lane];
+	for (uint32_t bi = blockIdx.x; bi < total; bi += gridDim.x) {
+		if (bi != blockIdx.x)
+			__syncthreads(); // the table of the block before is done with
+		const ZsLong L = z.dlong[bi];
+		const bool tab = L.tree < z.cap_trees && hd_build_table(dt, z.dtree + L.tree, lane);
+		__syncthreads();
+		const uint32_t q = (uint32_t) lane >> 4, j = lane & (ZSEG - 1);
+		const uint8_t *p = a.in + L.h.src;
+		uint8_t *out = z.ztmp + L.h.dst;
+		uint32_t len = 0, k = 0;
+		bool ok = tab;
+		{
+			const uint32_t s1 = p[0] | (p[1] << 8), s2 = p[2] | (p[3] << 8), s3 = p[4] | (p[5] << 8);
+			const uint32_t seg = (L.h.R + 3) / 4;
+			if (6ull + s1 + s2 + s3 >= L.h.cs || 3 * seg > L.h.R) {
+				ok = false;
+			} else {
+				const uint32_t sz[4] = { s1, s2, s3, L.h.cs - 6 - s1 - s2 - s3 };
+				p += 6;
+				for (uint32_t i = 0; i < q; i++)
+					p += sz[i];
+				len = sz[q];
+				k = q < 3 ? seg : L.h.R - 3 * seg;
+				out += (uint64_t) q * seg;
+			}
+			if (ok && (len == 0 || p[len - 1] == 0))
+				ok = false;
+		}
+		const int32_t B = ok ? (int32_t) (8 * (len - 1)) + (31 - __builtin_clz((uint32_t) p[len - 1])) : 0; // the stream's bits
+		const uint32_t ap = (uint32_t) (uintptr_t) p & 0x07FFFFFFu;
+		const int32_t c0 = (int32_t) (8 * ap) - 12;
+		int32_t flo = 0, fhi = (int32_t) len; // the frame's bytes, as offsets in the stream (k_zs_hdecode)
+		if (ok && L.read < a.nreads) {
+			const int64_t f0 = (int64_t) a.in_off[L.read] - (int64_t) (p - a.in);
+			const int64_t f1 = f0 + (int64_t) a.in_len[L.read];
+			if (f0 <= 0 && f1 >= (int64_t) len && f0 > -0x40000000ll && f1 < 0x40000000ll) {
+				flo = (int32_t) f0;
+				fhi = (int32_t) f1;
+			}
+		}
+		auto piece = [&](uint32_t ca) -> uint4 {
+			const int32_t o = (int32_t) (ca - ap);
+			uint4 v = make_uint4(0, 0, 0, 0);
+			if (o >= flo && o + 16 <= fhi) {
+				__builtin_memcpy(&v, p + o, 16);
+			} else if (o > -16 && o < (int32_t) len) {
+				uint32_t x[4] = { 0, 0, 0, 0 };
+				for (int e = 0; e < 16; e++)
+					if (o + e >= 0 && o + e < (int32_t) len)
+						x[e >> 2] |= (uint32_t) p[o + e] << (8 * (e & 3));
+				v = make_uint4(x[0], x[1], x[2], x[3]);
+			}
+			return v;
+		};
+		auto chunk_to_ring = [&](uint32_t ca, const uint4 *c4) {
+			uint32_t *d = myring + ((ca >> 2) & 16u);
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				d[4 * i] = c4[i].x;
+				d[4 * i + 1] = c4[i].y;
+				d[4 * i + 2] = c4[i].z;
+				d[4 * i + 3] = c4[i].w;
+			}
+		};
+		// the lane's segment: from `start` (bits of the stream not yet used) down to `lim`
+		const int32_t lim = (int32_t) (((int64_t) B * (ZSEG - 1 - (int) j)) / ZSEG);
+		int32_t start = j ? (int32_t) (((int64_t) B * (ZSEG - (int) j)) / ZSEG) : B;
+		int32_t exit_bp = start;  // where the lane's last code ended (<= lim)
+		uint32_t ncodes = 0;      // codes of the segment
+		bool over = false;        // the run wanted bits below the stream's first
+		// one run of the lanes with `on`; with `o`: the bytes are written there
+		auto run = [&](bool on, uint8_t *o) {
+			int32_t sp = start + c0;
+			const int32_t lsp = lim + c0;
+			uint32_t cc = (ap + (uint32_t) ((start > 0 ? start - 1 : 0) >> 3)) & ~63u;
+			if (on) {
+				uint4 c4[4];
+#pragma unroll
+				for (int i = 0; i < 4; i++)
+					c4[i] = piece(cc + 16 * i);
+				chunk_to_ring(cc, c4);
+#pragma unroll
+				for (int i = 0; i < 4; i++)
+					c4[i] = piece(cc - 64 + 16 * i);
+				chunk_to_ring(cc - 64, c4);
+			}
+			uint32_t w0 = (uint32_t) sp >> 5;
+			uint32_t lo = myring[w0 & 31u], hi = myring[(w0 + 1) & 31u];
+			uint4 pre[4];
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+				pre[i] = make_uint4(0, 0, 0, 0);
+			bool have_pre = false;
+			uint32_t n = 0, used = 0;
+			while (__any(on && sp > lsp)) {
+				const bool go = on && sp > lsp;
+				if (go && !have_pre) {
+					const int32_t oo = (int32_t) (cc - 128 - ap);
+					if (oo >= flo && oo + 64 <= fhi) {
+#pragma unroll
+						for (int i = 0; i < 4; i++)
+							__builtin_memcpy(&pre[i], p + oo + 16 * i, 16);
+					} else {
+#pragma unroll
+						for (int i = 0; i < 4; i++)
+							pre[i] = piece(cc - 128 + 16 * i);
+					}
+					have_pre = true;
+				}
+				uint32_t all[HD_SYMS / 4];
+#pragma unroll
+				for (int i = 0; i < (int) HD_SYMS / 4; i++)
+					all[i] = 0;
+				uint32_t c = 0;
+#pragma unroll
+				for (int i = 0; i < (int) HD_SYMS; i++) {
+					if (go && sp > lsp) {
+						const uint32_t below = myring[(w0 - 1) & 31u];
+						const uint32_t y = __builtin_amdgcn_alignbit(hi, lo, (uint32_t) sp);
+						const uint32_t e = *(lds_cu16p) (uintptr_t) ((y & 0xFFEu) | dtb);
+						const uint32_t nb = e >> 8;
+						used += nb;
+						sp = max(sp - (int32_t) nb, c0);
+						const uint32_t wn = (uint32_t) sp >> 5;
+						if (wn != w0) {
+							hi = lo;
+							lo = below;
+						}
+						w0 = wn;
+						all[i >> 2] |= (e & 0xFFu) << (8 * (i & 3));
+						c++;
+					}
+				}
+				if (go) {
+					const int32_t bp = sp - c0;
+					if (bp > 0) {
+						const uint32_t cn = (ap + (uint32_t) ((bp - 1) >> 3)) & ~63u;
+						if (cn != cc) {
+							chunk_to_ring(cc - 128, pre);
+							cc -= 64;
+							have_pre = false;
+						}
+					}
+					if (o) {
+#pragma unroll
+						for (int g = 0; g < (int) HD_SYMS / 16; g++) {
+							if (c >= 16u * g + 16u) {
+								const uint4 v = make_uint4(all[4 * g], all[4 * g + 1], all[4 * g + 2], all[4 * g + 3]);
+								__builtin_memcpy(o + n + 16 * g, &v, 16);
+							} else if (c > 16u * g) {
+#pragma unroll
+								for (int i = 0; i < 16; i++)
+									if (16u * g + i < c)
+										o[n + 16 * g + i] = (uint8_t) (all[4 * g + (i >> 2)] >> (8 * (i & 3)));
+							}
+						}
+					}
+					n += c;
+				}
+			}
+			if (on) {
+				exit_bp = sp - c0;
+				ncodes = n;
+				over = used > (uint32_t) (start - exit_bp); // (the clamp at bit 0 held the position back)
+			}
+		};
+		run(ok, nullptr);
+		for (int it = 0; it < ZSEG; it++) { // (every round fixes at least one more lane's start)
+			const int32_t above = __shfl_up(exit_bp, 1);
+			const int32_t want = j ? above : B;
+			const bool redo = ok && want != start;
+			if (!__any(redo))
+				break;
+			if (redo)
+				start = want;
+			run(redo, nullptr);
+		}
+		// ---- the codes in front of the lane's, in its stream; the stream's codes must be k and its last code end at bit 0
+		const uint32_t inc = wave_incl32(ok ? ncodes : 0u, lane);
+		const uint32_t excl = inc - (ok ? ncodes : 0u);
+		const uint32_t base = (uint32_t) __shfl((int) excl, (int) (q * ZSEG));
+		const uint32_t sum = (uint32_t) __shfl((int) inc, (int) (q * ZSEG + ZSEG - 1)) - base;
+		const int32_t last_exit = __shfl(exit_bp, (int) (q * ZSEG + ZSEG - 1));
+		const int32_t above = __shfl_up(exit_bp, 1);
+		bool good = ok && sum == k && last_exit == 0 && !over && (j ? above : B) == start;
+		// (one lane's verdict is its stream's: every lane of the stream must agree)
+		{
+			const unsigned long long g64 = __ballot(good);
+			const unsigned long long mask = 0xFFFFull << (q * ZSEG);
+			good = (g64 & mask) == mask;
+		}
+		run(good, out + (excl - base));
+		if (!good && j == 0 && L.read < a.nreads)
+			z.rd[L.read].mode = 2;
+	}
+}
+
 // Blocks with sequences (libzstd's own frames: the reference's streams, press.c:1462-1469): one wave
 // per frame carries them out in order - ll literals from the literals space, then ml bytes from off
 // bytes back in the content, which may be bytes the same wave has just written (a match may even
@@ -1691,6 +1933,7 @@ void launch_zstd_decode_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t
 	ktime_begin(1, s);
 	hipLaunchKernelGGL(k_zs_hdecode, dim3((z.cap_units + 1) / 2), dim3(64), 0, s, a, z);
 	ktime_end(1, s);
+	hipLaunchKernelGGL(k_zs_hdecode_long, dim3(z.cap_long < 8192 ? z.cap_long : 8192), dim3(64), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_exec, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
 }
 
