@@ -325,6 +325,43 @@ def test_device_reads_libzstd_frames(zm):
 
 
 @gpu
+def test_long_streams_of_libzstd_frames():
+    """ZSTD_compress puts up to 128 KiB of literals in a block: four streams of up to 32 768 codes, which the device
+    decodes with 16 lanes each (k_zs_hdecode_long: segments that synchronise themselves).  Reads of several such
+    blocks, noisy / tiny alphabet / a real-looking read, levels 1 and 3; then the same frames damaged inside a long stream."""
+    from honours_amd import press
+    z = _zstd()
+    oracle = _libs.oracle()
+    lib = press.load_library()
+    rng = np.random.default_rng(23)
+    reads = [rng.integers(300, 700, 600000).astype(np.int16),                      # ~5 blocks, nearly no matches
+             (np.cumsum(rng.integers(-3, 4, 300001)) + 500).astype(np.int16),     # tiny alphabet: short codes
+             rng.integers(480, 520, 131072 + 7).astype(np.int16)]
+    n, first = synth.read_lengths(3, 0, 64)
+    k = int(np.argmax(n))
+    reads.append(synth.synth_read(3, k, int(n[k]), int(first[k])))
+    for level in (1, 3):
+        frames = _libzstd_frames(z, oracle, reads, level)
+        back = press.depress_batch_host("zstd_svb_zd", frames, [len(s) for s in reads])
+        assert lib.press_hip_zstd_host_frames() == 0, level
+        for s, b in zip(reads, back):
+            assert b is not None and np.array_equal(b, s), "level %d n=%d" % (level, len(s))
+    frames = _libzstd_frames(z, oracle, reads, 1)
+    bad = list(frames)
+    for i in (0, 1):
+        x = bytearray(frames[i])
+        for at in (len(x) // 3, len(x) // 2):
+            x[at] ^= 0x24
+        bad[i] = bytes(x)
+    bad[2] = frames[2][:len(frames[2]) - 9]
+    back = press.depress_batch_host("zstd_svb_zd", bad, [len(s) for s in reads])
+    assert np.array_equal(back[3], reads[3])
+    assert back[2] is None
+    for i in (0, 1):  # a flipped bit breaks a stream's end or its code count (refused) or decodes to other samples
+        assert back[i] is None or not np.array_equal(back[i], reads[i])
+
+
+@gpu
 def test_device_refuses_damaged_frames():
     from honours_amd import press
     rng = np.random.default_rng(9)
