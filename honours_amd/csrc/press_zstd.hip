@@ -906,7 +906,8 @@ namespace {
 // divergence between reads); lane 0 writes what is found.
 constexpr uint32_t ZU = 8; // Huffman blocks per unit (32 streams: half a wave)
 constexpr uint32_t ZCOPY_INLINE = 2048; // raw blocks up to this size are copied by the walking wave itself
-constexpr uint32_t ZLONG_R = 32768;     // literals of a block from which each of its four streams is decoded by 16 lanes
+constexpr uint32_t ZLONG_R = zs::BLOCK_LITS + 1; // literals of a block from which each of its four streams is decoded by 16 lanes
+                                                 // (more than a block of this library's frames holds)
 struct DevSink {
 	const ZsBufs &z;
 	uint64_t in_base, out_base; // arena offset of the frame, ztmp offset of the content
@@ -920,6 +921,7 @@ struct DevSink {
 	uint32_t ntree_mine = 0;    // trees of this frame so far
 	uint32_t nreads = 0;        // reads of the batch
 	const uint8_t *in = nullptr; // the compressed arena
+	bool lean = false;           // the walk that leaves frames with sequences or long blocks to the one behind it
 	uint32_t first_xblk = 0, cur_xblk = 0, seq0 = 0; // blocks with sequences: the frame's chain, the one being filled
 
 	__device__ uint32_t take(uint32_t *ctr, uint32_t n = 1)
@@ -1105,7 +1107,9 @@ struct DevSink {
 	}
 	__device__ int64_t huf(uint64_t src, uint32_t cs, uint64_t dst, uint32_t R, bool four, bool lit)
 	{
-		if (four && R >= ZLONG_R) { // four long streams: a wave of its own (k_zs_hdecode_long)
+		if (four && R >= ZLONG_R) { // four long streams: a wave of its own (hd_long)
+			if (lean) // (no frame of this library has such a block: the lean walk stays lean)
+				return zs::W_SEQ;
 			const uint32_t i = take(&z.dctl->nlong);
 			if (i >= z.cap_long)
 				return zs::W_HOST;
@@ -1205,6 +1209,7 @@ __global__ __launch_bounds__(256, LEAN ? ZSWALK_LEAN_WAVES : ZSWALK_WAVES) void 
 	sink.lit_abs = z.lit_base + z.zoff[r];
 	sink.nreads = a.nreads;
 	sink.in = a.in;
+	sink.lean = LEAN;
 #ifdef HUF_STAMPS
 	sink.st_t = wt0;
 #endif
@@ -1341,20 +1346,21 @@ __device__ __forceinline__ bool hd_build_table(uint16_t *dt, const ZsTree *t, in
 // 7 blocks, so whole waves per read would leave more than half of the lanes idle - and the
 // kernel is bound by the instructions per decoded byte, not by latency): two tables in LDS,
 // one lane per bit stream
-__global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
+// (LDS of k_zs_hdecode: the two tables, always indexed by 11 stream bits - a shorter table log: every entry 2^(11 - log)
+// times -, each on a 4096-byte boundary: a look-up's LDS address is (window & 0xFFE) | base, one instruction; and a lane's
+// 128 stream bytes, odd stride: a lane's ring starts in its own bank)
+typedef uint16_t HdTables[2][2048];
+typedef uint32_t HdRings[64][33];
+__device__ __forceinline__ void hd_units(const DecodeArgs &a, const ZsBufs &z, HdTables &dt2, HdRings &ring, uint32_t wg)
 {
-	// the two tables, always indexed by 11 stream bits (a shorter table log: every entry 2^(11 - log) times), each on a
-	// 4096-byte boundary: a look-up's LDS address is (window & 0xFFE) | base - one instruction
-	__shared__ __attribute__((aligned(4096))) uint16_t dt2[2][2048];
-	__shared__ uint32_t ring[64][33]; // a lane's 128 stream bytes (odd stride: a lane's ring starts in its own bank)
 	const uint32_t total = z.dctl->nunits < z.cap_units ? z.dctl->nunits : z.cap_units;
-	if (2 * blockIdx.x >= total)
+	if (2 * wg >= total)
 		return;
 	const int lane = threadIdx.x;
 	ZSTAMP_DECL;
 	uint32_t cnth[2] = { 0, 0 }, readh[2] = { 0, 0 };
 	for (int hh = 0; hh < 2; hh++) {
-		const uint32_t uu = 2 * blockIdx.x + hh;
+		const uint32_t uu = 2 * wg + hh;
 		if (uu >= total)
 			continue;
 		const ZsUnit un = z.dunit[uu];
@@ -1368,7 +1374,7 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 	__syncthreads();
 	ZSTAMP(0); // tables
 	const int half = lane >> 5;
-	const uint32_t u = 2 * blockIdx.x + half;
+	const uint32_t u = 2 * wg + half;
 	typedef __attribute__((address_space(3))) const uint16_t *lds_cu16p;
 	const uint32_t dtb = (uint32_t) (uintptr_t) (lds_cu16p) dt2[half]; // (a multiple of 4096)
 	ZsUnit un;
@@ -1604,17 +1610,15 @@ __global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z)
 // the segments, counted on the way, give every lane its place in the output; a last run writes the bytes.  Same ring, same
 // step as k_zs_hdecode; a step is done under "not yet at the segment's end".
 constexpr int ZSEG = 16;
-__global__ __launch_bounds__(64) void k_zs_hdecode_long(DecodeArgs a, ZsBufs z)
+__device__ __forceinline__ void hd_long(const DecodeArgs &a, const ZsBufs &z, uint16_t *dt, HdRings &ring, uint32_t first, uint32_t stride)
 {
-	__shared__ __attribute__((aligned(4096))) uint16_t dt[2048];
-	__shared__ uint32_t ring[64][33];
 	const uint32_t total = z.dctl->nlong < z.cap_long ? z.dctl->nlong : z.cap_long;
 	const int lane = threadIdx.x;
 	typedef __attribute__((address_space(3))) const uint16_t *lds_cu16p;
 	const uint32_t dtb = (uint32_t) (uintptr_t) (lds_cu16p) dt;
 	uint32_t *myring = ring[lane];
-	for (uint32_t bi = blockIdx.x; bi < total; bi += gridDim.x) {
-		if (bi != blockIdx.x)
+	for (uint32_t bi = first; bi < total; bi += stride) {
+		if (bi != first)
 			__syncthreads(); // the table of the block before is done with
 		const ZsLong L = z.dlong[bi];
 		const bool tab = L.tree < z.cap_trees && hd_build_table(dt, z.dtree + L.tree, lane);
@@ -1810,6 +1814,19 @@ __global__ __launch_bounds__(64) void k_zs_hdecode_long(DecodeArgs a, ZsBufs z)
 	}
 }
 
+// One launch for both kinds of work, the long blocks' workgroups first (they run longest): a lane-per-stream wave and a
+// 16-lanes-per-stream wave are each a chain of look-ups with most of the chip's issue slots free - side by side they
+// take as long as the longer of the two (ZSTD_compress's frames: 0.70 + 0.59 ms one after the other).
+__global__ __launch_bounds__(64) void k_zs_hdecode(DecodeArgs a, ZsBufs z, uint32_t nlong_wgs)
+{
+	__shared__ __attribute__((aligned(4096))) HdTables dt2;
+	__shared__ HdRings ring;
+	if (blockIdx.x < nlong_wgs)
+		hd_long(a, z, dt2[0], ring, blockIdx.x, nlong_wgs);
+	else
+		hd_units(a, z, dt2, ring, blockIdx.x - nlong_wgs);
+}
+
 // Blocks with sequences (libzstd's own frames: the reference's streams, press.c:1462-1469): one wave
 // per frame carries them out in order - ll literals from the literals space, then ml bytes from off
 // bytes back in the content, which may be bytes the same wave has just written (a match may even
@@ -1931,9 +1948,9 @@ void launch_zstd_decode_frames(const DecodeArgs &a, const ZsBufs &z, hipStream_t
 	hipLaunchKernelGGL(k_zs_walk<false>, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_copy, dim3(z.cap_copy < 8192 ? z.cap_copy : 8192), dim3(256), 0, s, a, z);
 	ktime_begin(1, s);
-	hipLaunchKernelGGL(k_zs_hdecode, dim3((z.cap_units + 1) / 2), dim3(64), 0, s, a, z);
+	const uint32_t nlong_wgs = z.cap_long < 4096 ? z.cap_long : 4096;
+	hipLaunchKernelGGL(k_zs_hdecode, dim3(nlong_wgs + (z.cap_units + 1) / 2), dim3(64), 0, s, a, z, nlong_wgs);
 	ktime_end(1, s);
-	hipLaunchKernelGGL(k_zs_hdecode_long, dim3(z.cap_long < 8192 ? z.cap_long : 8192), dim3(64), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_exec, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
 }
 

@@ -1222,15 +1222,34 @@ template <class Sink, class Work> ZS_FN int64_t walk_frame(const uint8_t *fp, ui
 				if (!lastb)
 					return W_BAD;
 				int64_t bpos = 8ll * (int64_t) (sl - 1) + highbit(lastb); // bits left below the end mark
-				auto rd = [&](uint32_t n) -> uint32_t { // the n <= 32 bits below bpos, highest first; zeros below bit 0
-					uint32_t v = 0;
-					for (uint32_t i = 0; i < n; i++) {
-						bpos--;
-						uint32_t bit = 0;
-						if (bpos >= 0)
-							bit = (f[sb + (uint64_t) (bpos >> 3)] >> (bpos & 7)) & 1u;
-						v = (v << 1) | bit;
+				// (the next `have` bits wait in acc, the one read first on top; bytes come in behind a read, through the
+				// frame window.  Bit by bit through the window, this reader was most of the walk of a frame with sequences.)
+				uint32_t have = highbit(lastb);
+				uint64_t acc = lastb & ((1u << have) - 1u);
+				int64_t nextb = (int64_t) sl - 2; // the next byte of the section to take in
+				auto fill = [&]() {
+					while (have <= 56 && nextb >= 0) {
+						acc = (acc << 8) | f[sb + (uint64_t) nextb];
+						nextb--;
+						have += 8;
 					}
+				};
+				fill();
+				auto rd = [&](uint32_t n) -> uint32_t { // the n <= 32 bits below bpos, highest first; zeros below bit 0
+					if (!n)
+						return 0;
+					const uint32_t mask = n < 32 ? (1u << n) - 1u : 0xFFFFFFFFu;
+					uint32_t v;
+					if (have >= n) {
+						have -= n;
+						v = (uint32_t) (acc >> have) & mask;
+					} else { // (fill keeps more than 56 bits while bytes are left: the section ends here)
+						v = (uint32_t) (acc << (n - have)) & mask;
+						have = 0;
+						acc = 0;
+					}
+					bpos -= n;
+					fill();
 					return v;
 				};
 				uint32_t stl = rd(k.st[0].log), sto = rd(k.st[1].log), stm = rd(k.st[2].log);
