@@ -1198,6 +1198,7 @@ template <class Sink, class Work> ZS_FN int64_t walk_frame(const uint8_t *fp, ui
 				if (modes & 3)
 					return W_BAD;
 				const uint32_t dn = end - q < sizeof k.sdesc ? (uint32_t) (end - q) : (uint32_t) sizeof k.sdesc;
+				ZS_STAMP(sink, 7);
 				sink.fetch(k.sdesc, fp + q, dn);
 				uint32_t used_all = 0;
 				for (int which = 0; which < 3; which++) {
@@ -1212,6 +1213,7 @@ template <class Sink, class Work> ZS_FN int64_t walk_frame(const uint8_t *fp, ui
 				q += used_all;
 				if (q >= end)
 					return W_BAD;
+				ZS_STAMP(sink, 1); // (frames with sequences: the three FSE tables)
 				const int64_t e0 = sink.seq_block(nseq, lit_pos, R, dst);
 				if (e0)
 					return e0;
@@ -1304,6 +1306,7 @@ template <class Sink, class Work> ZS_FN int64_t walk_frame(const uint8_t *fp, ui
 				if (out + tail > cap)
 					return W_BAD;
 				sink.seq_end((uint32_t) tail);
+				ZS_STAMP(sink, 6); // (frames with sequences: the sequences read)
 				if (out + tail - dst > 131072) // Block_Maximum_Size also bounds what a block delivers (RFC 8878 3.1.1.2)
 					return W_BAD;
 				produced = (uint32_t) (out + tail - dst);
