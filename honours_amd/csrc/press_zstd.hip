@@ -1603,13 +1603,18 @@ __device__ __forceinline__ void hd_units(const DecodeArgs &a, const ZsBufs &z, H
 
 // Blocks with four LONG streams - ZSTD_compress's own frames, the reference's VBZ streams: 128-KiB blocks, 32 768 codes a
 // stream, and a lane per stream was a chain of 32 768 dependent look-ups (2.5 ms for 2048 reads, most lanes of the chip
-// without work).  Here a wave takes one block and 16 lanes share a stream: Huffman codes synchronise themselves - a decoder
-// started at ANY bit falls into step with the true code boundaries after a few codes - so lane j starts at bit B (16 - j) / 16
+// without work).  Here ZSEG lanes share a stream: Huffman codes synchronise themselves - a decoder
+// started at ANY bit falls into step with the true code boundaries after a few codes - so lane j starts at bit B (ZSEG - j) / ZSEG
 // (lane 0: at the stream's true start), runs down to where lane j + 1 started and notes where it got out; then every lane
 // runs its segment again from where the lane above got out, until no start moves any more (as a rule: once).  The codes of
 // the segments, counted on the way, give every lane its place in the output; a last run writes the bytes.  Same ring, same
 // step as k_zs_hdecode; a step is done under "not yet at the segment's end".
-constexpr int ZSEG = 16;
+#ifndef ZSEG_N
+#define ZSEG_N 32
+#endif
+constexpr int ZSEG = ZSEG_N;       // lanes per stream.  2048 / 1024 reads of ZSTD_compress's frames, whole depress call: 16 (a wave takes a
+                                   // block's four streams) 2.17 / 1.46 ms, 32 (two waves a block) 2.02 / 1.32, 64: 2.07 / 1.39
+constexpr int ZSPW = 64 / ZSEG;    // streams per wave
 __device__ __forceinline__ void hd_long(const DecodeArgs &a, const ZsBufs &z, uint16_t *dt, HdRings &ring, uint32_t first, uint32_t stride)
 {
 	const uint32_t total = z.dctl->nlong < z.cap_long ? z.dctl->nlong : z.cap_long;
@@ -1617,13 +1622,14 @@ __device__ __forceinline__ void hd_long(const DecodeArgs &a, const ZsBufs &z, ui
 	typedef __attribute__((address_space(3))) const uint16_t *lds_cu16p;
 	const uint32_t dtb = (uint32_t) (uintptr_t) (lds_cu16p) dt;
 	uint32_t *myring = ring[lane];
-	for (uint32_t bi = first; bi < total; bi += stride) {
+	for (uint32_t bi = first; bi < total * (4 / ZSPW); bi += stride) {
 		if (bi != first)
 			__syncthreads(); // the table of the block before is done with
-		const ZsLong L = z.dlong[bi];
+		const ZsLong L = z.dlong[bi / (4 / ZSPW)];
+		const uint32_t q0 = (bi % (4 / ZSPW)) * ZSPW; // the wave's first stream of the block
 		const bool tab = L.tree < z.cap_trees && hd_build_table(dt, z.dtree + L.tree, lane);
 		__syncthreads();
-		const uint32_t q = (uint32_t) lane >> 4, j = lane & (ZSEG - 1);
+		const uint32_t qw = (uint32_t) lane / ZSEG, q = q0 + qw, j = lane & (ZSEG - 1); // stream in the wave, in the block; segment
 		const uint8_t *p = a.in + L.h.src;
 		uint8_t *out = z.ztmp + L.h.dst;
 		uint32_t len = 0, k = 0;
@@ -1797,15 +1803,15 @@ __device__ __forceinline__ void hd_long(const DecodeArgs &a, const ZsBufs &z, ui
 		// ---- the codes in front of the lane's, in its stream; the stream's codes must be k and its last code end at bit 0
 		const uint32_t inc = wave_incl32(ok ? ncodes : 0u, lane);
 		const uint32_t excl = inc - (ok ? ncodes : 0u);
-		const uint32_t base = (uint32_t) __shfl((int) excl, (int) (q * ZSEG));
-		const uint32_t sum = (uint32_t) __shfl((int) inc, (int) (q * ZSEG + ZSEG - 1)) - base;
-		const int32_t last_exit = __shfl(exit_bp, (int) (q * ZSEG + ZSEG - 1));
+		const uint32_t base = (uint32_t) __shfl((int) excl, (int) (qw * ZSEG));
+		const uint32_t sum = (uint32_t) __shfl((int) inc, (int) (qw * ZSEG + ZSEG - 1)) - base;
+		const int32_t last_exit = __shfl(exit_bp, (int) (qw * ZSEG + ZSEG - 1));
 		const int32_t above = __shfl_up(exit_bp, 1);
 		bool good = ok && sum == k && last_exit == 0 && !over && (j ? above : B) == start;
 		// (one lane's verdict is its stream's: every lane of the stream must agree)
 		{
 			const unsigned long long g64 = __ballot(good);
-			const unsigned long long mask = 0xFFFFull << (q * ZSEG);
+			const unsigned long long mask = (ZSEG == 64 ? ~0ull : (1ull << (ZSEG & 63)) - 1ull) << (qw * (ZSEG & 63));
 			good = (g64 & mask) == mask;
 		}
 		run(good, out + (excl - base));
