@@ -335,8 +335,8 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 			(void) lookback(a.gran, t, d.j, 0, last);
 			if (last && threadIdx.x == 0)
 				a.out_len[d.read] = CFAIL64;
-			if (HIST && threadIdx.x == 0)
-				a.zkcnt[t] = 0;
+			if (HIST && last && threadIdx.x == 0)
+				a.zkcnt[t - d.j] = 0;
 		}
 		__syncthreads(); // every wave has read s_ticket before thread 0 overwrites it
 		continue;
@@ -370,6 +370,7 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 	uint32_t kmask = 0;  // sub-tiles that need the slow path (exceptions or a ragged tail)
 	uint32_t omask = 0;  // S5: sub-tiles with a 17-bit value
 	uint32_t etot = 0;   // exceptions in this wave's quarter (uniform)
+	uint32_t knz1 = 0;   // HIST: key bytes of this wave's quarter that are not zero (uniform)
 #pragma unroll
 	for (int k = 0; k < CK; k++) {
 		const uint32_t i0 = ws + k * SUB + lane * 8;
@@ -424,6 +425,13 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 		if (bo)
 			omask |= 1u << k;
 		if (bx) {
+			if (HIST) { // key bytes that will not be zero: a lane's eight values are one (svb16) or two (svb32) of them
+				if (KEY2)
+					knz1 += (uint32_t) (__popcll(__ballot(((z[k].x | z[k].y) & 0xFF00FF00u) != 0)) +
+							     __popcll(__ballot(((z[k].z | z[k].w) & 0xFF00FF00u) != 0)));
+				else
+					knz1 += (uint32_t) __popcll(__ballot(hi != 0));
+			}
 			// exact count of the extra bytes: one popcount of a ballot per key bit; a 17-bit
 			// value has two of them whatever its low half looks like
 			const uint32_t zz[4] = { z[k].x, z[k].y, z[k].z, z[k].w };
@@ -439,24 +447,32 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 	}
 
 	// ---- exceptions before this wave: within the chunk (LDS) and before the chunk (look-back)
-	if (lane == 0)
+	if (lane == 0) {
 		s_wtot[w] = etot;
+		if (HIST)
+			s_knz[w] = knz1;
+	}
 	__syncthreads();
 	const uint32_t t0 = uni(s_wtot[0]), t1 = uni(s_wtot[1]), t2 = uni(s_wtot[2]), t3 = uni(s_wtot[3]);
+	// HIST: the look-back carries two counts - exceptions below bit 40, key bytes that are not zero above (a read has
+	// fewer than 2^32 of the first and 2^22 of the second)
+	const uint32_t q0 = HIST ? uni(s_knz[0]) : 0u, q1 = HIST ? uni(s_knz[1]) : 0u, q2 = HIST ? uni(s_knz[2]) : 0u,
+		       q3 = HIST ? uni(s_knz[3]) : 0u;
 	if (w == 0) {
-		const uint64_t e = lookback(a.gran, t, d.j, (uint64_t) t0 + t1 + t2 + t3, last);
+		const uint64_t e = lookback(a.gran, t, d.j, ((uint64_t) t0 + t1 + t2 + t3) | ((uint64_t) (q0 + q1 + q2 + q3) << 40), last);
 		if (lane == 0)
 			s_excl = e;
 	}
 	__syncthreads();
-	const uint64_t ebefore = uni64(s_excl);
+	const uint64_t ebefore = uni64(s_excl) & ((1ull << 40) - 1);
+	uint32_t kbefore = (uint32_t) (uni64(s_excl) >> 40) + (w > 0 ? q0 : 0u) + (w > 1 ? q1 : 0u) + (w > 2 ? q2 : 0u); // list slot of the wave's next key byte
 	uint64_t ebase = ebefore + (w > 0 ? t0 : 0u) + (w > 1 ? t1 : 0u) + (w > 2 ? t2 : 0u);
 	if (last && threadIdx.x == 0)
 		a.out_len[d.read] = (uint64_t) (S5 ? 4 : 0) + klen + n + ebefore + t0 + t1 + t2 + t3;
 
 	// ---- phase 2: keys and data
 	uint8_t *data = out + klen;
-	uint32_t knz = 0; // HIST: key bytes of this wave's quarter that are not zero (uniform)
+
 #pragma unroll
 	for (int k = 0; k < CK; k++) {
 		const uint32_t i0 = ws + k * SUB + lane * 8;
@@ -512,27 +528,49 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 			wide &= (1u << nv) - 1u;
 			key &= ~wide;
 		}
+		// the lane's key byte(s)
+		uint32_t k0 = key, k1 = 0;
+		if (KEY2) {
+			k0 = 0;
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				k0 |= (((key >> q) & 1u) | (((wide >> q) & 1u) << 1)) << (2 * q);
+				k1 |= (((key >> (q + 4)) & 1u) | (((wide >> (q + 4)) & 1u) << 1)) << (2 * q);
+			}
+		}
+		if (!nv)
+			k0 = 0;
+		if (nv <= 4)
+			k1 = 0;
 		const uint32_t cnt = __popc(key) + 2u * __popc(wide);
-		const uint32_t inc = wave_incl_scan32(cnt);
-		const uint32_t tot = (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+		const uint32_t kc = HIST ? (k0 != 0) + (k1 != 0) : 0u; // (one scan for both: a sub-tile has at most 1536 extra bytes)
+		const uint32_t inc2 = wave_incl_scan32(cnt | (kc << 16));
+		const uint32_t inc = inc2 & 0xFFFFu;
+		const uint32_t tot2 = (uint32_t) __builtin_amdgcn_readlane((int) inc2, 63);
+		const uint32_t tot = tot2 & 0xFFFFu;
 		uint8_t *p = data + ebase + i0 + (inc - cnt);
+		if (HIST && kc) { // the read's list of key bytes that are not zero (press_zstd.hip: RLE blocks between them)
+			uint32_t slot = kbefore + (inc2 >> 16) - kc;
+			const uint32_t kpos = KEY2 ? i0 >> 2 : i0 >> 3;
+			if (k0) {
+				a.ex_pos[d.sig_off + slot] = kpos;
+				a.ex_val[d.sig_off + slot] = k0;
+				slot++;
+			}
+			if (k1) {
+				a.ex_pos[d.sig_off + slot] = kpos + 1;
+				a.ex_val[d.sig_off + slot] = k1;
+			}
+		}
+		if (HIST)
+			kbefore += tot2 >> 16;
 		if (nv) {
 			if (!KEY2) {
 				out[i0 >> 3] = (uint8_t) key;
-				if (HIST)
-					knz += (uint32_t) __popcll(__ballot(key != 0));
 			} else {
-				uint32_t k0 = 0, k1 = 0;
-#pragma unroll
-				for (int q = 0; q < 4; q++) {
-					k0 |= (((key >> q) & 1u) | (((wide >> q) & 1u) << 1)) << (2 * q);
-					k1 |= (((key >> (q + 4)) & 1u) | (((wide >> (q + 4)) & 1u) << 1)) << (2 * q);
-				}
 				out[i0 >> 2] = (uint8_t) k0;
 				if (nv > 4)
 					out[(i0 >> 2) + 1] = (uint8_t) k1;
-				if (HIST)
-					knz += (uint32_t) (__popcll(__ballot(k0 != 0)) + __popcll(__ballot(nv > 4 && k1 != 0)));
 			}
 			if (HIST) {
 #pragma unroll
@@ -570,11 +608,9 @@ __global__ __launch_bounds__(CWG) void k_svb_encode_chunked(BatchArgs a)
 	}
 	if (HIST) { // the chunk's counts to its read's; a thread clears what it has read (the next chunk counts behind
 		    // three barriers)
-		if (lane == 0)
-			s_knz[w] = knz;
 		__syncthreads();
-		if (threadIdx.x == 0)
-			a.zkcnt[t] = s_knz[0] + s_knz[1] + s_knz[2] + s_knz[3];
+		if (last && threadIdx.x == 0) // the read's count of such key bytes (k_zs_table takes it from its first chunk's slot)
+			a.zkcnt[t - d.j] = (uint32_t) (uni64(s_excl) >> 40) + q0 + q1 + q2 + q3;
 		uint32_t c = 0;
 		for (int i = 0; i < 16; i++) {
 			c += s_hist[i][threadIdx.x];

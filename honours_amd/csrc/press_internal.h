@@ -147,7 +147,8 @@ struct BatchArgs {
 	uint32_t *first_chunk;    // [nreads] id of the first chunk of read r (exception-split encode)
 	uint32_t *zhist;          // zstd compositions: [nreads][256] occurrences of the data bytes, counted where the svb
 	                          // encoder has them in registers (zeroed by the caller; NULL for the other methods)
-	uint32_t *zkcnt;          // ... and [max_chunks] the key bytes of chunk c that are not zero (with zhist)
+	uint32_t *zkcnt;          // ... and [max_chunks] at a read's FIRST chunk: the read's key bytes that are not zero (with zhist;
+	                          // their positions and values are listed in ex_pos / ex_val of the read, in order)
 };
 
 struct HufTile {             // one tile of a read's Huffman payload (press_huffman.hip), 32 bytes

@@ -389,20 +389,26 @@ __global__ __launch_bounds__(256) void k_zs_table(BatchArgs a, ZsBufs z)
 	// the counts live where build_table keeps the nodes' parents: it reads them (into Work::w) before it writes those
 	static_assert(sizeof(L.k.parent) >= 256 * sizeof(uint32_t) && offsetof(zs::Work, parent) % 4 == 0, "counts in Work::parent");
 	uint32_t *cnt = reinterpret_cast<uint32_t *>(L.k.parent);
-	// ---- ranks of the key lists
+	// ---- the key bytes that are not zero: svb streams - counted and listed by the encoder (the read's count in its first
+	// chunk's slot); the exception-split stream has no keys (k_zs_keycount / k_zs_keylist: nothing to list)
 	{
 		const uint32_t n = a.nsamp[r];
 		const uint32_t nch = (n + CHUNK - 1) / CHUNK, c0 = a.first_chunk[r];
-		uint32_t carry = 0;
-		for (uint32_t i = 0; i < nch; i += 64) {
-			const uint32_t v = i + lane < nch ? z.kcnt[c0 + i + lane] : 0;
-			const uint32_t inc = wave_incl32(v, lane);
-			if (i + lane < nch)
-				z.kbase[c0 + i + lane] = carry + inc - v;
-			carry += __shfl(inc, 63);
+		if (z.kdiv) {
+			if (lane == 0)
+				rd->knz = nch && rd->mode == 0 ? z.kcnt[c0] : 0u;
+		} else {
+			uint32_t carry = 0;
+			for (uint32_t i = 0; i < nch; i += 64) {
+				const uint32_t v = i + lane < nch ? z.kcnt[c0 + i + lane] : 0;
+				const uint32_t inc = wave_incl32(v, lane);
+				if (i + lane < nch)
+					z.kbase[c0 + i + lane] = carry + inc - v;
+				carry += __shfl(inc, 63);
+			}
+			if (lane == 0)
+				rd->knz = carry;
 		}
-		if (lane == 0)
-			rd->knz = carry;
 	}
 	// ---- the table
 	uint32_t mine[4], present = 0;
@@ -883,7 +889,8 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 	if (!z.kdiv)
 		hipLaunchKernelGGL(k_zs_keycount, dim3(a.max_chunks), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_table, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
-	hipLaunchKernelGGL(k_zs_keylist, dim3(a.max_chunks), dim3(256), 0, s, a, z);
+	if (!z.kdiv)
+		hipLaunchKernelGGL(k_zs_keylist, dim3(a.max_chunks), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_bits, dim3(z.max_blocks), dim3(256), 0, s, z);
 	hipLaunchKernelGGL(k_zs_plan, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
 	ktime_begin(0, s);
