@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Stress of the static-Huffman batch path on the GPU (gpurun -- python3 tools/stress_huff.py [ITER] [READS]):
+"""Stress of the static-Huffman batch path on the GPU (gpurun -- python3 tools/stress_huff.py [ITER] [READS] [METHOD,METHOD]):
 different synthetic batches (seed, read count, fixed or natural lengths), each compressed and decompressed
 REPEAT times on the device; every decode must give back the samples and every encode the same bytes as the
 first one of its batch (the kernels hand out work by tickets and atomics: no run may depend on their order).
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def stress(iters, reads, repeat=6, verbose=True):
+def stress(iters, reads, repeat=6, verbose=True, methods=("shuffman_vbe21_zd", "shuffman_vbsse21_zd")):
     """-> number of batches run; raises AssertionError at the first difference"""
     import torch
 
@@ -29,7 +29,7 @@ def stress(iters, reads, repeat=6, verbose=True):
         R = int(rng.integers(1, reads + 1))
         fixed = None if it % 3 else int(rng.integers(1, 300000))
         b = bench.Batch(torch, press, synth, seed, int(rng.integers(0, 1 << 20)), R, dev, fixed)
-        for m in ("shuffman_vbe21_zd", "shuffman_vbsse21_zd"):
+        for m in methods:
             caps, d_out, d_out_off, d_in_off = b.arena(torch, press, m)
             first = None
             for k in range(repeat):
@@ -65,7 +65,8 @@ def stress(iters, reads, repeat=6, verbose=True):
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     reads = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
-    print("all", stress(iters, reads), "batches ok")
+    methods = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("shuffman_vbe21_zd", "shuffman_vbsse21_zd")
+    print("all", stress(iters, reads, methods=methods), "batches ok", methods)
 
 
 if __name__ == "__main__":
