@@ -92,7 +92,7 @@ struct Ctx {
 	bool use_user = false;
 	// scratch shared by both modes
 	DevBuf meta, ex_pos, ex_val, low, huff, chunks, gran, ctl, first_chunk, htiles, htrec, hrec, hlist, hread, hwave, hbits, hend, hmin, cbits;
-	DevBuf ztmp, zoff, zoff4, zlen, zhist, ztab, zfirst, zblk, zsbits, zbpos, zbflag, zkcnt, zkbase, zrd, znb, zn, zdcopy, zdhuf, zdunit, zdtree, zdlong, zdctl, zdseq, zdxblk; // zstd frames
+	DevBuf ztmp, zoff, zoff4, zlen, zhist, ztab, zfirst, zblk, zsbits, zbpos, zbflag, zkcnt, zrd, znb, zn, zdcopy, zdhuf, zdunit, zdtree, zdlong, zdctl, zdseq, zdxblk; // zstd frames
 	// staging for host-pointer calls
 	DevBuf sig, off, nsamp, arena, arena_off, lens, lens2, outn, dense, dense_off;
 	uint64_t zs_total = 0; // total_samples of the batch in flight (sizes of the zstd scratch)
@@ -448,7 +448,6 @@ void zs_bufs(ZsBufs &z, uint64_t total_samples, uint32_t nreads, int method = PR
 	z.bpos = (uint32_t *) g.zbpos.p;
 	z.bflag = (uint8_t *) g.zbflag.p;
 	z.kcnt = (uint32_t *) g.zkcnt.p;
-	z.kbase = (uint32_t *) g.zkbase.p;
 	z.rd = (ZsRead *) g.zrd.p;
 	z.nblocks = (uint32_t *) g.znb.p;
 	z.max_blocks = max_zblocks_of(total_samples, nreads);
@@ -502,7 +501,7 @@ int reserve_scratch(int method, uint64_t total_samples, uint32_t nreads, bool de
 		if (g.ztmp.reserve(zs_tmp_bytes(method, total_samples, nreads)) || g.zoff.reserve(nr * 8) || g.zoff4.reserve(nr * 8) ||
 		    g.zlen.reserve(nr * 8) || g.zhist.reserve(nr * 1024) || g.ztab.reserve(nr * sizeof(zs::Table)) ||
 		    g.zfirst.reserve(nr * 4) || g.zblk.reserve(mb * 4) || g.zsbits.reserve(mb * 16) || g.zbpos.reserve(mb * 4) ||
-		    g.zbflag.reserve(mb) || g.zkcnt.reserve(mc * 4) || g.zkbase.reserve(mc * 4) ||
+		    g.zbflag.reserve(mb) || g.zkcnt.reserve(mc * 4) ||
 		    g.zrd.reserve(nr * sizeof(ZsRead)) || g.znb.reserve(64) ||
 		    g.ex_pos.reserve((total_samples + 64) * 4) || g.ex_val.reserve((total_samples + 64) * 4))
 			return PRESS_HIP_EHIP;

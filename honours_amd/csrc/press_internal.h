@@ -259,8 +259,7 @@ struct ZsBufs {
 	uint4 *sbits;         // [max_blocks] code bits of the four streams of a block
 	uint32_t *bpos;       // [max_blocks] frame offset of the block
 	uint8_t *bflag;       // [max_blocks] 1: Huffman, 2: carries the tree, 4: last block of the frame
-	uint32_t *kcnt;       // [max_chunks] non-zero key bytes in a chunk's keys
-	uint32_t *kbase;      // [max_chunks] ... in the chunks of the read in front of it
+	uint32_t *kcnt;       // [max_chunks] at a read's first chunk: its key bytes that are not zero (BatchArgs::zkcnt)
 	ZsRead *rd;           // [nreads]
 	uint32_t *nblocks;    // [1]
 	uint32_t max_blocks;

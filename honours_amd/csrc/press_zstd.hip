@@ -14,7 +14,7 @@
 // serial model that must give the same bytes.
 //
 // Kernels (encode): k_zs_layout -> [svb encode into ztmp] -> k_zs_blocks -> k_zs_blockmap ->
-// k_zs_hist + k_zs_keycount -> k_zs_table -> k_zs_keylist + k_zs_bits -> k_zs_plan ->
+// [k_zs_hist: the exception-split stream; the svb encoder counts its bytes itself] -> k_zs_table -> k_zs_bits -> k_zs_plan ->
 // k_zs_encode (+ k_zs_rawframes for reads that do not shrink).
 
 #include "press_internal.h"
@@ -241,95 +241,6 @@ __global__ __launch_bounds__(256) void k_zs_hist(ZsBufs z)
 		atomicAdd(&z.hist[(uint64_t) u.r * 256 + threadIdx.x], c);
 }
 
-__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x)
-{
-	return (uint32_t) __builtin_popcount((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u);
-}
-
-// key bytes of chunk c of its read that are not zero; thread t looks at 32 of them
-__device__ __forceinline__ uint32_t key_load(const ZsBufs &z, const ChunkDesc *dp, uint32_t *x, uint32_t *first)
-{
-	const uint32_t r = dp->read, j = dp->j;
-	const uint32_t kch = z.kdiv ? CHUNK / z.kdiv : 0; // key bytes per chunk
-	const uint32_t end = (j + 1) * kch < z.rd[r].nk ? (j + 1) * kch : z.rd[r].nk;
-	const uint32_t nk = end; // (the keys of this chunk end here)
-	const uint8_t *keys = z.ztmp + z.zoff[r] + z.rd[r].plen;
-	const uint32_t k0 = j * kch + threadIdx.x * 32;
-	*first = k0;
-	uint32_t cnt = 0;
-#pragma unroll
-	for (int q = 0; q < 2; q++) {
-		const uint32_t at = k0 + 16 * q;
-		uint4 v = make_uint4(0, 0, 0, 0);
-		if (at + 16 <= nk) {
-			__builtin_memcpy(&v, keys + at, 16);
-		} else if (at < nk) {
-			uint8_t tmp[16] = { 0 };
-			for (uint32_t e = 0; e < nk - at; e++)
-				tmp[e] = keys[at + e];
-			__builtin_memcpy(&v, tmp, 16);
-		}
-		x[4 * q] = v.x;
-		x[4 * q + 1] = v.y;
-		x[4 * q + 2] = v.z;
-		x[4 * q + 3] = v.w;
-		cnt += nonzero_bytes(v.x) + nonzero_bytes(v.y) + nonzero_bytes(v.z) + nonzero_bytes(v.w);
-	}
-	return cnt;
-}
-
-__global__ __launch_bounds__(256) void k_zs_keycount(BatchArgs a, ZsBufs z)
-{
-	__shared__ uint32_t ws[4];
-	const uint32_t c = blockIdx.x;
-	if (c >= a.ctl->nchunks)
-		return;
-	const ChunkDesc *dp = a.chunks + c;
-	if (z.rd[dp->read].mode) {
-		if (threadIdx.x == 0)
-			z.kcnt[c] = 0;
-		return;
-	}
-	uint32_t x[8], first;
-	const uint32_t cnt = wave_sum32(key_load(z, dp, x, &first));
-	if ((threadIdx.x & 63) == 0)
-		ws[threadIdx.x >> 6] = cnt;
-	__syncthreads();
-	if (threadIdx.x == 0)
-		z.kcnt[c] = ws[0] + ws[1] + ws[2] + ws[3];
-}
-
-// the non-zero key bytes of a read in order: position in ex_pos[off[r] + rank], value in ex_val
-__global__ __launch_bounds__(256) void k_zs_keylist(BatchArgs a, ZsBufs z)
-{
-	__shared__ uint32_t ws[4];
-	const uint32_t c = blockIdx.x;
-	if (c >= a.ctl->nchunks || z.kcnt[c] == 0)
-		return;
-	const ChunkDesc *dp = a.chunks + c;
-	uint32_t x[8], first;
-	const uint32_t cnt = key_load(z, dp, x, &first);
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-	const uint32_t inc = wave_incl32(cnt, lane);
-	if (lane == 63)
-		ws[w] = inc;
-	__syncthreads();
-	uint32_t rank = z.kbase[c] + inc - cnt;
-	for (int i = 0; i < w; i++)
-		rank += ws[i];
-	if (!cnt)
-		return;
-	const uint64_t base = a.off[dp->read];
-	for (int e = 0; e < 32; e++) {
-		const uint32_t v = (x[e >> 2] >> (8 * (e & 3))) & 0xFFu;
-		if (v) {
-			a.ex_pos[base + rank] = first + e;
-			a.ex_val[base + rank] = v;
-			rank++;
-		}
-	}
-}
-
 // the lanes of a wave inside zs::build_table
 struct WavePar {
 	uint32_t l;
@@ -389,26 +300,11 @@ __global__ __launch_bounds__(256) void k_zs_table(BatchArgs a, ZsBufs z)
 	// the counts live where build_table keeps the nodes' parents: it reads them (into Work::w) before it writes those
 	static_assert(sizeof(L.k.parent) >= 256 * sizeof(uint32_t) && offsetof(zs::Work, parent) % 4 == 0, "counts in Work::parent");
 	uint32_t *cnt = reinterpret_cast<uint32_t *>(L.k.parent);
-	// ---- the key bytes that are not zero: svb streams - counted and listed by the encoder (the read's count in its first
-	// chunk's slot); the exception-split stream has no keys (k_zs_keycount / k_zs_keylist: nothing to list)
-	{
+	// ---- the key bytes that are not zero: counted and listed by the svb encoder (the read's count in its first chunk's
+	// slot); the exception-split stream has no keys
+	if (lane == 0) {
 		const uint32_t n = a.nsamp[r];
-		const uint32_t nch = (n + CHUNK - 1) / CHUNK, c0 = a.first_chunk[r];
-		if (z.kdiv) {
-			if (lane == 0)
-				rd->knz = nch && rd->mode == 0 ? z.kcnt[c0] : 0u;
-		} else {
-			uint32_t carry = 0;
-			for (uint32_t i = 0; i < nch; i += 64) {
-				const uint32_t v = i + lane < nch ? z.kcnt[c0 + i + lane] : 0;
-				const uint32_t inc = wave_incl32(v, lane);
-				if (i + lane < nch)
-					z.kbase[c0 + i + lane] = carry + inc - v;
-				carry += __shfl(inc, 63);
-			}
-			if (lane == 0)
-				rd->knz = carry;
-		}
+		rd->knz = z.kdiv && n ? z.kcnt[a.first_chunk[r]] : 0u;
 	}
 	// ---- the table
 	uint32_t mine[4], present = 0;
@@ -886,11 +782,7 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 			   z.blk_read);
 	if (!z.kdiv) // (the exception-split stream: counted from ztmp)
 		hipLaunchKernelGGL(k_zs_hist, dim3(z.max_blocks), dim3(256), 0, s, z);
-	if (!z.kdiv)
-		hipLaunchKernelGGL(k_zs_keycount, dim3(a.max_chunks), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_table, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
-	if (!z.kdiv)
-		hipLaunchKernelGGL(k_zs_keylist, dim3(a.max_chunks), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_bits, dim3(z.max_blocks), dim3(256), 0, s, z);
 	hipLaunchKernelGGL(k_zs_plan, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
 	ktime_begin(0, s);
