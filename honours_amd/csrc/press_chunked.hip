@@ -1511,8 +1511,12 @@ __global__ __launch_bounds__(CWG) void k_ex_list(BatchArgs a)
 }
 
 // Pass B, plain one-byte stream (press.c:2717-2725): one workgroup per chunk, any order.
+// HIST (zstd_hasgam_vbsse21_zdq, press_zstd.hip): the bytes are counted per read while a lane holds them, as in
+// k_svb_encode_chunked<.., HIST> (BatchArgs::zhist).
+template <bool HIST = false>
 __global__ __launch_bounds__(CWG) void k_low_encode_chunked(BatchArgs a)
 {
+	__shared__ uint32_t s_hist[HIST ? 16 : 1][256];
 	const uint32_t t = blockIdx.x;
 	if (t >= a.ctl->nchunks)
 		return;
@@ -1525,8 +1529,13 @@ __global__ __launch_bounds__(CWG) void k_low_encode_chunked(BatchArgs a)
 	const int lane = threadIdx.x & 63;
 	const int w = (int) uni(threadIdx.x >> 6);
 	const uint32_t ws = d.j * CHUNK + w * WAVE_SAMPLES;
-	if (ws >= n)
-		return;
+	uint32_t *myhist = s_hist[HIST ? 4 * w + (lane & 3) : 0];
+	if (HIST) {
+		for (int i = 0; i < 16; i++)
+			s_hist[i][threadIdx.x] = 0;
+		__syncthreads();
+	}
+	if (ws < n) {
 	const int q = (int) uni(m->q);
 	const int16_t *in = a.sig + d.sig_off;
 	// one-byte value of sample i (i >= 1) goes to stream[(i - 1) - #exceptions before i]
@@ -1552,6 +1561,13 @@ __global__ __launch_bounds__(CWG) void k_low_encode_chunked(BatchArgs a)
 				v.x = __builtin_amdgcn_perm(z[k].y, z[k].x, 0x06040200);
 				v.y = __builtin_amdgcn_perm(z[k].w, z[k].z, 0x06040200);
 				__builtin_memcpy(stream + (i0 - 1 - eb), &v, 8);
+				if (HIST) {
+#pragma unroll
+					for (int e = 0; e < 4; e++) {
+						atomicAdd(&myhist[(v.x >> (8 * e)) & 0xFFu], 1u);
+						atomicAdd(&myhist[(v.y >> (8 * e)) & 0xFFu], 1u);
+					}
+				}
 			}
 			continue;
 		}
@@ -1564,10 +1580,23 @@ __global__ __launch_bounds__(CWG) void k_low_encode_chunked(BatchArgs a)
 		uint64_t p = (uint64_t) (i0 ? i0 - 1 : 0) - (eb + inc - c);
 #pragma unroll
 		for (int h = 0; h < 8; h++) {
-			if ((uint32_t) h < nv && !((em >> h) & 1u) && !(i0 == 0 && h == 0))
-				stream[p++] = (uint8_t) (zz[h >> 1] >> (16 * (h & 1)));
+			if ((uint32_t) h < nv && !((em >> h) & 1u) && !(i0 == 0 && h == 0)) {
+				const uint32_t b = (zz[h >> 1] >> (16 * (h & 1))) & 0xFFu;
+				stream[p++] = (uint8_t) b;
+				if (HIST)
+					atomicAdd(&myhist[b], 1u);
+			}
 		}
 		eb += (uint32_t) __builtin_amdgcn_readlane((int) inc, 63);
+	}
+	} // (a wave whose quarter lies behind the read's end has nothing to write)
+	if (HIST) {
+		__syncthreads();
+		uint32_t c = 0;
+		for (int i = 0; i < 16; i++)
+			c += s_hist[i][threadIdx.x];
+		if (c)
+			atomicAdd(&a.zhist[(uint64_t) d.read * 256 + threadIdx.x], c);
 	}
 }
 
@@ -2194,7 +2223,7 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, int ent, hipStream_t 
 	hipLaunchKernelGGL(k_ex_list, dim3((a.max_chunks + 3) / 4), dim3(CWG), 0, s, a);
 	launch_ex_section(a, fmt, ent, s);
 	if (ent >= 2) { // range coder: the one-byte values go to a temporary, one lane (order 1: one workgroup) per read codes them
-		hipLaunchKernelGGL(k_low_encode_chunked, dim3(a.max_chunks), dim3(CWG), 0, s, a);
+		hipLaunchKernelGGL(k_low_encode_chunked<false>, dim3(a.max_chunks), dim3(CWG), 0, s, a);
 		ktime_begin(0, s);
 		if (ent == 2)
 			launch_rcs_encode(a, s);
@@ -2208,8 +2237,10 @@ void launch_ex_encode_chunked(const BatchArgs &a, int fmt, int ent, hipStream_t 
 	ktime_begin(0, s);
 	if (huff)
 		hipLaunchKernelGGL(k_huff_encode_chunked, dim3(a.max_chunks), dim3(CWG), 0, s, a);
+	else if (a.zhist)
+		hipLaunchKernelGGL(k_low_encode_chunked<true>, dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	else
-		hipLaunchKernelGGL(k_low_encode_chunked, dim3(a.max_chunks), dim3(CWG), 0, s, a);
+		hipLaunchKernelGGL(k_low_encode_chunked<false>, dim3(a.max_chunks), dim3(CWG), 0, s, a);
 	ktime_end(0, s);
 }
 

@@ -14,7 +14,7 @@
 // serial model that must give the same bytes.
 //
 // Kernels (encode): k_zs_layout -> [svb encode into ztmp] -> k_zs_blocks -> k_zs_blockmap ->
-// [k_zs_hist: the exception-split stream; the svb encoder counts its bytes itself] -> k_zs_table -> k_zs_bits -> k_zs_plan ->
+// [the encoder of the inner stream counts its data bytes itself] -> k_zs_table -> k_zs_bits -> k_zs_plan ->
 // k_zs_encode (+ k_zs_rawframes for reads that do not shrink).
 
 #include "press_internal.h"
@@ -199,46 +199,6 @@ __device__ __forceinline__ BlkU load_blk(const ZsBufs &z, uint32_t b)
 	u.R = nd - u.j * ZB < ZB ? nd - u.j * ZB : ZB;
 	u.data = z.ztmp + z.zoff[u.r] + rd->plen + rd->nk + (uint64_t) u.j * ZB;
 	return u;
-}
-
-// byte histogram of one data block, added to the read's
-__global__ __launch_bounds__(256) void k_zs_hist(ZsBufs z)
-{
-	// 16 copies (4 per wave, by lane): nanopore deltas are peaked, and lanes that hit the same
-	// counter in one instruction are served one after the other
-	__shared__ uint32_t h[16][256];
-	const uint32_t b = blockIdx.x;
-	if (b >= *z.nblocks)
-		return;
-	const BlkU u = load_blk(z, b);
-	uint32_t *mine = h[4 * (threadIdx.x >> 6) + (threadIdx.x & 3)];
-	for (int i = 0; i < 16; i++)
-		h[i][threadIdx.x] = 0;
-	__syncthreads();
-	const uint32_t i0 = threadIdx.x * 64;
-#pragma unroll
-	for (int q = 0; q < 4; q++) {
-		const uint32_t at = i0 + 16 * q;
-		if (at + 16 <= u.R) {
-			uint4 v;
-			__builtin_memcpy(&v, u.data + at, 16);
-			const uint32_t x[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-			for (int d = 0; d < 4; d++)
-#pragma unroll
-				for (int e = 0; e < 4; e++)
-					atomicAdd(&mine[(x[d] >> (8 * e)) & 0xFFu], 1u);
-		} else {
-			for (uint32_t e = at; e < u.R && e < at + 16; e++)
-				atomicAdd(&mine[u.data[e]], 1u);
-		}
-	}
-	__syncthreads();
-	uint32_t c = 0;
-	for (int i = 0; i < 16; i++)
-		c += h[i][threadIdx.x];
-	if (c)
-		atomicAdd(&z.hist[(uint64_t) u.r * 256 + threadIdx.x], c);
 }
 
 // the lanes of a wave inside zs::build_table
@@ -768,7 +728,7 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 	sv.out_off = z.kdiv ? z.zoff4 : z.zoff;
 	sv.out_len = z.zlen;
 	(void) hipMemsetAsync(z.hist, 0, (size_t) a.nreads * 1024, s);
-	sv.zhist = z.kdiv ? z.hist : nullptr; // svb: the data bytes - and the key bytes that are not zero - are counted where they are made
+	sv.zhist = z.hist; // the data bytes - and (svb) the key bytes that are not zero - are counted where they are made
 	sv.zkcnt = z.kcnt;
 	ktime_mute(true);
 	if (z.kdiv)
@@ -780,8 +740,6 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 			   z.max_blocks, z.kdiv, z.ztmp, z.zoff, a.meta);
 	hipLaunchKernelGGL(k_zs_blockmap, dim3((z.max_blocks + 255) / 256), dim3(256), 0, s, z.first_blk, a.nreads, z.nblocks,
 			   z.blk_read);
-	if (!z.kdiv) // (the exception-split stream: counted from ztmp)
-		hipLaunchKernelGGL(k_zs_hist, dim3(z.max_blocks), dim3(256), 0, s, z);
 	hipLaunchKernelGGL(k_zs_table, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
 	hipLaunchKernelGGL(k_zs_bits, dim3(z.max_blocks), dim3(256), 0, s, z);
 	hipLaunchKernelGGL(k_zs_plan, dim3((a.nreads + 3) / 4), dim3(256), 0, s, a, z);
