@@ -880,12 +880,12 @@ struct DevSink {
 			}
 		}
 	}
-	__device__ void fill(uint64_t src, uint64_t dst, uint32_t n, bool lit)
+	__device__ void fill(uint64_t, uint64_t dst, uint32_t n, bool lit, uint32_t value)
 	{
 		if (!n)
 			return;
 		uint8_t *d = z.ztmp + (lit ? lit_abs : out_base) + dst;
-		const uint8_t v = in[in_base + src];
+		const uint8_t v = (uint8_t) value; // (from the walk's window: a load from the arena here was a memory round trip per block)
 		const uint32_t v4 = v * 0x01010101u, lane = threadIdx.x & 63;
 		// bytes up to a 16-byte boundary, 16 at a time, the rest
 		const uint32_t head = (uint32_t) ((16 - ((uintptr_t) d & 15)) & 15);

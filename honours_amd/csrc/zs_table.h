@@ -995,7 +995,7 @@ ZS_FN uint32_t seq_table(int which, uint32_t mode, const uint8_t *p, uint32_t av
 //   sink.fetch(dst, src, n)           n frame bytes for the walk itself (dst: the window / the description buffer)
 //   sink.copy(src, dst, n, lit)       n bytes of the frame at offset src are the content at dst (lit: the bytes at
 //                                     dst of the frame's LITERALS space instead - a block with sequences)
-//   sink.fill(src, dst, n, lit)       the byte at src, n times
+//   sink.fill(src, dst, n, lit, v)    the byte at src (= v: the walk has it in its window), n times
 //   sink.tree(w, tl) -> 0 / W_*       the Huffman table from here on: weights of the 256 bytes, table log
 //   sink.huf(src, csize, dst, R, four, lit) -> 0 / W_*   Huffman-coded literals: csize bytes at src (jump table
 //                                     first when `four`) are R bytes at dst
@@ -1088,7 +1088,7 @@ template <class Sink, class Work> ZS_FN int64_t walk_frame(const uint8_t *fp, ui
 			if (at + 1 > len || dst + bs > cap)
 				return W_BAD;
 			ZS_STAMP(sink, 7);
-			sink.fill(at, dst, bs, false);
+			sink.fill(at, dst, bs, false, f[at]);
 			ZS_STAMP(sink, 1);
 			at += 1;
 			dst += bs;
@@ -1152,7 +1152,7 @@ template <class Sink, class Work> ZS_FN int64_t walk_frame(const uint8_t *fp, ui
 			if (lt == 0) {
 				sink.copy(src, ldst, R, seqs);
 			} else if (lt == 1) {
-				sink.fill(src, ldst, R, seqs);
+				sink.fill(src, ldst, R, seqs, f[src]);
 			} else {
 				if (lt == 2) {
 					uint8_t *w = k.w;

@@ -233,7 +233,7 @@ struct HostSink {
 		return lits + dst;
 	}
 	void copy(uint64_t src, uint64_t dst, uint32_t n, bool lit) { memcpy(where(dst, n, lit), f + src, n); }
-	void fill(uint64_t src, uint64_t dst, uint32_t n, bool lit) { memset(where(dst, n, lit), f[src], n); }
+	void fill(uint64_t src, uint64_t dst, uint32_t n, bool lit, uint32_t v) { (void) src; memset(where(dst, n, lit), (int) v, n); } // (v: the byte at src, handed over by the walk)
 	int64_t seq_block(uint32_t, uint64_t lit, uint32_t R, uint64_t dst)
 	{
 		(void) where(lit, R, true);
