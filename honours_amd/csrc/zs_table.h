@@ -64,12 +64,9 @@ struct Work {
 	uint32_t fail;
 };
 
-ZS_FN uint32_t highbit(uint32_t v)
+ZS_FN uint32_t highbit(uint32_t v) // position of the highest set bit; 0 for 0
 {
-	uint32_t r = 0;
-	while (v >>= 1)
-		r++;
-	return r;
+	return v ? 31u - (uint32_t) __builtin_clz(v) : 0u; // (a loop over the bits here was ten steps per cell of every FSE table)
 }
 
 // little-endian bit writer into a small byte buffer: bits collect in a register, whole bytes
