@@ -13,9 +13,9 @@
 // tests/: libzstd decodes these frames to the reference's buffer; oracle/zsframe_model.cpp is a
 // serial model that must give the same bytes.
 //
-// Kernels (encode): k_zs_layout -> [svb encode into ztmp] -> k_zs_blocks -> k_zs_blockmap ->
-// [the encoder of the inner stream counts its data bytes itself] -> k_zs_table -> k_zs_bits -> k_zs_plan ->
-// k_zs_encode (+ k_zs_rawframes for reads that do not shrink).
+// Kernels (encode): k_zs_layout -> [the inner stream into ztmp; its encoder counts the data bytes per read and (svb) counts
+// and lists the key bytes that are not zero: press_chunked.hip, HIST] -> k_zs_blocks -> k_zs_blockmap -> k_zs_table ->
+// k_zs_bits -> k_zs_plan -> k_zs_encode (+ k_zs_rawframes for reads that do not shrink).
 
 #include "press_internal.h"
 #include "zs_table.h"
@@ -760,11 +760,12 @@ void launch_zstd_encode(const BatchArgs &a, const ZsBufs &z, hipStream_t s)
 
 // ==================================================================== decode
 //
-// k_zs_layout -> k_zs_walk (one lane per read: zs::walk_frame checks the frame and lists its
-// pieces) -> k_zs_copy (raw / RLE pieces) + k_zs_hdecode (one lane per Huffman stream) ->
-// k_zs_exec (one wave per frame: the sequences of libzstd's own frames) -> [the caller lets libzstd do
-// the frames the walk left to it: dictionaries, 12-bit Huffman tables, several frames in one stream]
-// -> k_zs_finish -> svb-zd decode.  Neither this library's frames nor ZSTD_compress's need libzstd.
+// k_zs_layout -> k_zs_walk<lean> (one wave per read: zs::walk_frame checks the frame, carries out fills and short copies
+// and lists the other pieces; frames with sequences or long blocks are left to) -> k_zs_walk<full> -> k_zs_copy (long raw
+// blocks) + k_zs_hdecode (one lane per Huffman stream - hd_units - and, for blocks with more literals than this library
+// writes, 32 lanes per stream - hd_long -, side by side in one launch) -> k_zs_exec (one wave per frame: the sequences of
+// libzstd's own frames) -> [the caller lets libzstd do the frames the walk left to it: dictionaries, 12-bit Huffman tables,
+// several frames in one stream] -> k_zs_finish -> svb-zd decode.  Neither this library's frames nor ZSTD_compress's need libzstd.
 
 namespace {
 
