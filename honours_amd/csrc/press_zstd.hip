@@ -1146,7 +1146,15 @@ __global__ __launch_bounds__(256) void k_zs_copy(DecodeArgs a, ZsBufs z)
 		copy_piece(a, z, z.dcopy[i]);
 }
 
-constexpr uint32_t HD_SYMS = 32; // codes per round: at most 44 bytes + 12 bits of look-ahead, less than a 64-byte chunk
+#ifndef HD_SYMS_N
+#define HD_SYMS_N 32
+#endif
+constexpr uint32_t HD_SYMS = HD_SYMS_N; // codes per round: at most 11 bits each + 12 bits of look-ahead - less than a chunk
+                                        // (k_zs_hdecode on config 3 with 16 / 32 / 64: 1.35 / 1.14-1.19 / 1.27 ms - 12 / 9 / 6 waves per CU)
+constexpr uint32_t HD_CH = 2 * HD_SYMS; // bytes of a chunk of the ring (on a boundary of as many)
+constexpr int HD_PC = HD_CH / 16;       // 16-byte pieces of a chunk
+constexpr uint32_t HD_RD = HD_CH / 2;   // dwords of a lane's ring (two chunks)
+static_assert(HD_SYMS % 16 == 0 && 11 * HD_SYMS + 12 < 8 * HD_CH, "a round stays inside the lower chunk");
 // The decoding table of a tree in LDS: bytes in the order of the weights (zs::huf_build_dtable), always indexed by 11 stream
 // bits (a shorter table log: every entry 2^(11 - log) times); dt[i] = byte | bits << 8.  All 64 lanes of a wave; false: the
 // weights are not a tree (cannot happen: read_tree checked them).
@@ -1217,7 +1225,7 @@ __device__ __forceinline__ bool hd_build_table(uint16_t *dt, const ZsTree *t, in
 // times -, each on a 4096-byte boundary: a look-up's LDS address is (window & 0xFFE) | base, one instruction; and a lane's
 // 128 stream bytes, odd stride: a lane's ring starts in its own bank)
 typedef uint16_t HdTables[2][2048];
-typedef uint32_t HdRings[64][33];
+typedef uint32_t HdRings[64][HD_RD + 1];
 __device__ __forceinline__ void hd_units(const DecodeArgs &a, const ZsBufs &z, HdTables &dt2, HdRings &ring, uint32_t wg)
 {
 	const uint32_t total = z.dctl->nunits < z.cap_units ? z.dctl->nunits : z.cap_units;
@@ -1335,9 +1343,9 @@ __device__ __forceinline__ void hd_units(const DecodeArgs &a, const ZsBufs &z, H
 		return v;
 	};
 	auto chunk_to_ring = [&](uint32_t ca, const uint4 *c4) { // chunk address ca (a multiple of 64)
-		uint32_t *d = myring + ((ca >> 2) & 16u);
+		uint32_t *d = myring + ((ca >> 2) & (HD_RD / 2));
 #pragma unroll
-		for (int j = 0; j < 4; j++) {
+		for (int j = 0; j < HD_PC; j++) {
 			d[4 * j] = c4[j].x;
 			d[4 * j + 1] = c4[j].y;
 			d[4 * j + 2] = c4[j].z;
@@ -1347,16 +1355,16 @@ __device__ __forceinline__ void hd_units(const DecodeArgs &a, const ZsBufs &z, H
 	// the chunk that holds the stream's highest bit still to come, and the one below it
 	uint32_t cc = 0; // (address of the upper chunk)
 	if (active) {
-		cc = (ap + (uint32_t) ((bp > 0 ? bp - 1 : 0) >> 3)) & ~63u;
-		uint4 c4[4];
+		cc = (ap + (uint32_t) ((bp > 0 ? bp - 1 : 0) >> 3)) & ~(HD_CH - 1u);
+		uint4 c4[HD_PC];
 #pragma unroll
-		for (int j = 0; j < 4; j++)
+		for (int j = 0; j < HD_PC; j++)
 			c4[j] = piece(cc + 16 * j);
 		chunk_to_ring(cc, c4);
 #pragma unroll
-		for (int j = 0; j < 4; j++)
-			c4[j] = piece(cc - 64 + 16 * j);
-		chunk_to_ring(cc - 64, c4);
+		for (int j = 0; j < HD_PC; j++)
+			c4[j] = piece(cc - HD_CH + 16 * j);
+		chunk_to_ring(cc - HD_CH, c4);
 	}
 	// sp = the (address-based) bit position ONE BELOW the eleven bits a look-up wants: the window cut at sp has the table
 	// index in bits 1 .. 11 - twice the index, the entry's byte offset.  The chain from one code to the next is cut -
@@ -1365,26 +1373,26 @@ __device__ __forceinline__ void hd_units(const DecodeArgs &a, const ZsBufs &z, H
 	const int32_t c0 = (int32_t) (8 * ap) - 12;
 	int32_t sp = bp + c0;
 	uint32_t w0 = (uint32_t) sp >> 5;
-	uint32_t lo = myring[w0 & 31u], hi = myring[(w0 + 1) & 31u];
-	uint4 pre[4]; // the chunk below the ring's two
+	uint32_t lo = myring[w0 & (HD_RD - 1u)], hi = myring[(w0 + 1) & (HD_RD - 1u)];
+	uint4 pre[HD_PC]; // the chunk below the ring's two
 	bool have_pre = false;
 #pragma unroll
-	for (int j = 0; j < 4; j++)
+	for (int j = 0; j < HD_PC; j++)
 		pre[j] = make_uint4(0, 0, 0, 0);
 	ZSTAMP(1); // stream headers, first chunks
 	for (uint32_t done = 0; __any(active && done < k); done += HD_SYMS) {
 		const bool go = active && done < k;
 		const uint32_t cnt = go ? (k - done < HD_SYMS ? k - done : HD_SYMS) : 0;
 		if (go && !have_pre) { // asked for now, wanted a round or more from now
-			const int32_t o = (int32_t) (cc - 128 - ap);
-			if (o >= flo && o + 64 <= fhi) { // (the rule: the whole chunk is inside the frame)
+			const int32_t o = (int32_t) (cc - 2 * HD_CH - ap);
+			if (o >= flo && o + (int32_t) HD_CH <= fhi) { // (the rule: the whole chunk is inside the frame)
 #pragma unroll
-				for (int j = 0; j < 4; j++)
+				for (int j = 0; j < HD_PC; j++)
 					__builtin_memcpy(&pre[j], p + o + 16 * j, 16);
 			} else {
 #pragma unroll
-				for (int j = 0; j < 4; j++)
-					pre[j] = piece(cc - 128 + 16 * j);
+				for (int j = 0; j < HD_PC; j++)
+					pre[j] = piece(cc - 2 * HD_CH + 16 * j);
 			}
 			have_pre = true;
 		}
@@ -1392,7 +1400,7 @@ __device__ __forceinline__ void hd_units(const DecodeArgs &a, const ZsBufs &z, H
 		const int32_t bp0 = bp;
 		uint32_t used = 0;
 		auto step = [&]() -> uint32_t { // one code: its byte
-			const uint32_t below = myring[(w0 - 1) & 31u];
+			const uint32_t below = myring[(w0 - 1) & (HD_RD - 1u)];
 			const uint32_t y = __builtin_amdgcn_alignbit(hi, lo, (uint32_t) sp); // shift = low 5 bits
 			const uint32_t e = *(lds_cu16p) (uintptr_t) ((y & 0xFFEu) | dtb);
 			const uint32_t nb = e >> 8;
@@ -1431,10 +1439,10 @@ __device__ __forceinline__ void hd_units(const DecodeArgs &a, const ZsBufs &z, H
 		ZSTAMP(3); // decode
 		// ---- has the position left the upper chunk?  (at most 44 bytes a round: by one chunk)
 		if (go && bp > 0) {
-			const uint32_t cn = (ap + (uint32_t) ((bp - 1) >> 3)) & ~63u;
+			const uint32_t cn = (ap + (uint32_t) ((bp - 1) >> 3)) & ~(HD_CH - 1u);
 			if (cn != cc) {
-				chunk_to_ring(cc - 128, pre);
-				cc -= 64;
+				chunk_to_ring(cc - 2 * HD_CH, pre);
+				cc -= HD_CH;
 				have_pre = false;
 			}
 		}
@@ -1545,9 +1553,9 @@ __device__ __forceinline__ void hd_long(const DecodeArgs &a, const ZsBufs &z, ui
 			return v;
 		};
 		auto chunk_to_ring = [&](uint32_t ca, const uint4 *c4) {
-			uint32_t *d = myring + ((ca >> 2) & 16u);
+			uint32_t *d = myring + ((ca >> 2) & (HD_RD / 2));
 #pragma unroll
-			for (int i = 0; i < 4; i++) {
+			for (int i = 0; i < HD_PC; i++) {
 				d[4 * i] = c4[i].x;
 				d[4 * i + 1] = c4[i].y;
 				d[4 * i + 2] = c4[i].z;
@@ -1564,38 +1572,38 @@ __device__ __forceinline__ void hd_long(const DecodeArgs &a, const ZsBufs &z, ui
 		auto run = [&](bool on, uint8_t *o) {
 			int32_t sp = start + c0;
 			const int32_t lsp = lim + c0;
-			uint32_t cc = (ap + (uint32_t) ((start > 0 ? start - 1 : 0) >> 3)) & ~63u;
+			uint32_t cc = (ap + (uint32_t) ((start > 0 ? start - 1 : 0) >> 3)) & ~(HD_CH - 1u);
 			if (on) {
-				uint4 c4[4];
+				uint4 c4[HD_PC];
 #pragma unroll
-				for (int i = 0; i < 4; i++)
+				for (int i = 0; i < HD_PC; i++)
 					c4[i] = piece(cc + 16 * i);
 				chunk_to_ring(cc, c4);
 #pragma unroll
-				for (int i = 0; i < 4; i++)
-					c4[i] = piece(cc - 64 + 16 * i);
-				chunk_to_ring(cc - 64, c4);
+				for (int i = 0; i < HD_PC; i++)
+					c4[i] = piece(cc - HD_CH + 16 * i);
+				chunk_to_ring(cc - HD_CH, c4);
 			}
 			uint32_t w0 = (uint32_t) sp >> 5;
-			uint32_t lo = myring[w0 & 31u], hi = myring[(w0 + 1) & 31u];
-			uint4 pre[4];
+			uint32_t lo = myring[w0 & (HD_RD - 1u)], hi = myring[(w0 + 1) & (HD_RD - 1u)];
+			uint4 pre[HD_PC];
 #pragma unroll
-			for (int i = 0; i < 4; i++)
+			for (int i = 0; i < HD_PC; i++)
 				pre[i] = make_uint4(0, 0, 0, 0);
 			bool have_pre = false;
 			uint32_t n = 0, used = 0;
 			while (__any(on && sp > lsp)) {
 				const bool go = on && sp > lsp;
 				if (go && !have_pre) {
-					const int32_t oo = (int32_t) (cc - 128 - ap);
-					if (oo >= flo && oo + 64 <= fhi) {
+					const int32_t oo = (int32_t) (cc - 2 * HD_CH - ap);
+					if (oo >= flo && oo + (int32_t) HD_CH <= fhi) {
 #pragma unroll
-						for (int i = 0; i < 4; i++)
+						for (int i = 0; i < HD_PC; i++)
 							__builtin_memcpy(&pre[i], p + oo + 16 * i, 16);
 					} else {
 #pragma unroll
-						for (int i = 0; i < 4; i++)
-							pre[i] = piece(cc - 128 + 16 * i);
+						for (int i = 0; i < HD_PC; i++)
+							pre[i] = piece(cc - 2 * HD_CH + 16 * i);
 					}
 					have_pre = true;
 				}
@@ -1607,7 +1615,7 @@ __device__ __forceinline__ void hd_long(const DecodeArgs &a, const ZsBufs &z, ui
 #pragma unroll
 				for (int i = 0; i < (int) HD_SYMS; i++) {
 					if (go && sp > lsp) {
-						const uint32_t below = myring[(w0 - 1) & 31u];
+						const uint32_t below = myring[(w0 - 1) & (HD_RD - 1u)];
 						const uint32_t y = __builtin_amdgcn_alignbit(hi, lo, (uint32_t) sp);
 						const uint32_t e = *(lds_cu16p) (uintptr_t) ((y & 0xFFEu) | dtb);
 						const uint32_t nb = e >> 8;
@@ -1626,10 +1634,10 @@ __device__ __forceinline__ void hd_long(const DecodeArgs &a, const ZsBufs &z, ui
 				if (go) {
 					const int32_t bp = sp - c0;
 					if (bp > 0) {
-						const uint32_t cn = (ap + (uint32_t) ((bp - 1) >> 3)) & ~63u;
+						const uint32_t cn = (ap + (uint32_t) ((bp - 1) >> 3)) & ~(HD_CH - 1u);
 						if (cn != cc) {
-							chunk_to_ring(cc - 128, pre);
-							cc -= 64;
+							chunk_to_ring(cc - 2 * HD_CH, pre);
+							cc -= HD_CH;
 							have_pre = false;
 						}
 					}
