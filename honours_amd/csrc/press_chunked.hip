@@ -891,6 +891,8 @@ __global__ __launch_bounds__(CWG) void k_svb_decode_chunked(DecodeArgs a)
 
 	const int lane = threadIdx.x & 63;
 	const int w = (int) uni(threadIdx.x >> 6);
+	if (blockIdx.x >= uni(a.ctl->nchunks))
+		return; // (the grid is an upper bound: surplus workgroups draw no ticket - blockIdx only COUNTS the workgroups)
 #ifdef DEC_BLOCKIDX_TICKET
 	// DIAGNOSTIC BUILD ONLY (tools/build_variants.sh "tkb:-DDEC_BLOCKIDX_TICKET"): what the ticket in front of every
 	// workgroup costs.  Chunk ids from blockIdx rely on workgroups starting in the order of their ids, which HIP does not
